@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec (whole node) for one EM iteration = align (K1 log-likes + K2 Viterbi)
++ acc-stats (K3) [+ RCCL all-reduce of the accumulators when N > 1] on BASELINE.json's
+5000-pdf x 64-Gaussian, 40-dim synthetic workload (configs[3]).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; one rank per GPU (RANK/LOCAL_RANK/
+WORLD_SIZE from the env under torch.distributed.run); rank 0 prints ONE JSON line.
+Strong scaling as configs[3] states it: the 100k-utterance set is SHARDED across the N ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="tri5000x64")
+    ap.add_argument("--utts", type=int, default=100000, help="total utterances over all ranks")
+    ap.add_argument("--beam", type=float, default=200.0)
+    ap.add_argument("--retry-beam", type=float, default=0.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20230418)
+    return ap.parse_args()
+
+
+def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
+    """The oracle (CPU restatement, kind="port") timed on a bounded sample of the SAME workload:
+    AlignUtteranceWrapper + acc-stats per utterance, one thread -- the reference's execution model."""
+    from oracle import oracle as orc
+
+    om = orc.OModel(model.gauss_off, gc, model.means_invvars, model.inv_vars)
+    oa = orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids)
+    g = dict(ut.graphs)
+    g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[g["ilabel"]], g["weight"]).astype(np.float32)
+    frames = 0
+    n = 0
+    t0 = time.perf_counter()
+    for u in range(feats_host["n"]):
+        og = orc.OGraph.from_set(g, u)
+        f = feats_host["feats"][ut.frame_off[u]: ut.frame_off[u + 1]]
+        r = orc.align_utterance(og, om, model.id2pdf, f, acoustic_scale=0.1)
+        if (r["status"] & 1) == 0:
+            orc.acc_stats_ali(om, model.id2pdf, f, r["ali"], oa)
+        frames += f.shape[0]
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 4:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} utterances ({frames} frames) of rank 0's shard, oracle/khg_oracle.c "
+                      f"(gcc -O2, 1 thread): FasterDecoder+GMM decodable+acc-stats, {dt:.1f}s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from kaldi_hmm_gmm_amd import Context, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet, synth
+    from kaldi_hmm_gmm_amd import _lib
+    import ctypes as C
+
+    P, G, D = synth.CONFIGS[args.config]
+    model = synth.make_model(P, G, D, seed=args.seed)
+    gc = np.zeros(model.weights.shape[0], np.float32)
+    _lib.check(_lib.lib.khg_compute_gconsts(P, D, _lib.ptr(model.gauss_off, C.c_int32), _lib.ptr(model.weights, C.c_float),
+                                            _lib.ptr(model.inv_vars, C.c_float), _lib.ptr(model.means_invvars, C.c_float),
+                                            _lib.ptr(gc, C.c_float), None))
+    # AddTransitionProbs scales of the yesno recipe (egs/yesno/train.py:179-181)
+    cost = np.zeros(model.num_tids + 1, np.float32)
+    _lib.check(_lib.lib.khg_scaled_trans_cost(model.num_tids, _lib.ptr(model.log_probs, C.c_float),
+                                              _lib.ptr(model.non_self_loop_log_probs, C.c_float),
+                                              _lib.ptr(model.id2state, C.c_int32), _lib.ptr(model.is_self_loop, C.c_uint8),
+                                              1.0, 0.1, _lib.ptr(cost, C.c_float)))
+    n_local = args.utts // world + (1 if rank < args.utts % world else 0)
+    ut = synth.make_utts(model, n_local, seed=args.seed + 1000 + rank, feats=False)
+    dev = torch.device("cuda", local)
+    feats = synth.sample_feats_torch(model, ut.frame_pdf, args.seed + 2000 + rank, dev)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+    ctx = Context(local, stream=stream.cuda_stream)
+    dm = DeviceModel(ctx, model.gauss_off, gc, model.means_invvars, model.inv_vars)
+    tm = DeviceTransitions(ctx, model.id2pdf)
+    tm.set_trans_cost(cost)
+    us = UtteranceSet(ctx, tm, ut.frame_off, (feats.data_ptr(), feats), dim=D, graphs=ut.graphs)
+    accs = DeviceAccs(ctx, dm, tm)
+    acc_t = accs.as_torch() if world > 1 else None
+
+    poff, _ = us.pdf_lists()
+    T = np.diff(ut.frame_off)
+    npdf = np.diff(poff)
+    frames_local = int(ut.frame_off[-1])
+    k1_flops = float((T * npdf).sum()) * (4.0 * D * G + 5.0 * G)  # alignment log-likes
+
+    k1_ms = []
+
+    def step(timed):
+        accs.zero()
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        us.loglikes(dm)
+        if timed:
+            e1.record(stream)
+        us.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=False)
+        us.acc_stats(dm, tm, accs)
+        if world > 1:
+            dist.all_reduce(acc_t)
+        if timed:
+            k1_ms.append((e0, e1))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    frames_total = frames_local
+    if world > 1:
+        t = torch.tensor([dt, float(frames_local)], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        frames_total = int(t[1])
+    k1_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in k1_ms]))
+
+    if rank == 0:
+        res = accs.download()
+        status = None
+        out = {
+            "metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss",
+            "value": frames_total * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P} pdfs x {G} Gauss, dim {D}, {args.utts} utterances "
+                                   f"({frames_total} frames) sharded over {world} GPU(s), beam {args.beam:g}, "
+                                   f"acoustic_scale 0.1, mean pdfs/utt {npdf.mean():.1f}",
+                       "frames_per_step": frames_total, "utterances": args.utts},
+            "roofline": {"bound": "mfma", "kernel": "k1_loglikes", "achieved": k1_flops / (k1_avg_ms * 1e-3) / 1e12,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": k1_flops / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops},
+            "check": {"acc_total_frames": res["total_frames"] , "avg_loglike_per_frame":
+                      res["total_log_like"] / max(res["total_frames"], 1.0)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            ncpu = min(n_local, 256)
+            fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

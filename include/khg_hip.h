@@ -1,0 +1,197 @@
+/* include/khg_hip.h -- C-ABI of the MI355X (gfx950) HMM-GMM EM hot path.
+ *
+ * Drop-in boundary for csukuangfj/kaldi-hmm-gmm's align + acc-stats + M-step path.  Every
+ * entry point names the reference interface it replaces (paths relative to
+ * /root/reference/kaldi-hmm-gmm/, "csrc/" = the core library, "python/csrc/" = the pybind11
+ * layer a maintainer would bind these from).
+ *
+ * Conventions: plain pointers and sizes only; `_h` = host pointer, `_d` = device pointer;
+ * every function returns 0 on success or a negative KHG_E_* code, with the message available
+ * from khg_last_error() (thread-local).  Reference KHG_ERR / KHG_ASSERT (csrc/log.h:46-83,
+ * std::runtime_error) map to KHG_E_RUNTIME.  Handles are opaque; work is stream-ordered on the
+ * context's HIP stream; there is no hidden CPU fallback: without a usable GPU every compute
+ * entry point fails with KHG_E_HIP.
+ */
+#ifndef KHG_HIP_H_
+#define KHG_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KHG_OK 0
+#define KHG_E_ARG (-1)      /* invalid argument / shape mismatch                              */
+#define KHG_E_HIP (-2)      /* HIP runtime error (no device, OOM, launch failure)             */
+#define KHG_E_RUNTIME (-3)  /* the reference would throw std::runtime_error here              */
+#define KHG_E_UNSUPPORTED (-4)
+
+typedef struct khg_ctx khg_ctx;
+typedef struct khg_model khg_model;
+typedef struct khg_tm khg_tm;
+typedef struct khg_utts khg_utts;
+typedef struct khg_accs khg_accs;
+
+const char *khg_last_error(void);
+int khg_version(void);
+
+/* ---- per-device context ------------------------------------------------------------- */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL to let the
+ * context create its own non-blocking stream. */
+int khg_ctx_create(int device, void *stream, khg_ctx **out);
+int khg_ctx_destroy(khg_ctx *ctx);
+int khg_ctx_sync(khg_ctx *ctx);
+
+/* ---- acoustic model ------------------------------------------------------------------- */
+/* AmDiagGmm (csrc/am-diag-gmm.h:96) as flat ragged arrays: pdf p owns Gaussians
+ * [gauss_off[p], gauss_off[p+1]) with DiagGmm's exponential-form parameters
+ * (csrc/diag-gmm.h:243-256).  gconsts must be valid (khg_compute_gconsts).  Uploads the
+ * MFMA tile image used by K1 and the row-major copy used by K3. */
+int khg_model_create(khg_ctx *ctx, int32_t num_pdfs, int32_t dim, const int32_t *gauss_off_h,
+                     const float *gconsts_h, const float *means_invvars_h,
+                     const float *inv_vars_h, khg_model **out);
+int khg_model_destroy(khg_model *m);
+
+/* ---- transition information ------------------------------------------------------------ */
+/* TransitionInformation::TransitionIdToPdf table (csrc/transition-information.h:71-73,
+ * csrc/transition-model.cc:278-302): id2pdf_h[0..num_tids], entry 0 unused. */
+int khg_tm_create(khg_ctx *ctx, int32_t num_tids, const int32_t *id2pdf_h, khg_tm **out);
+/* AddTransitionProbs (csrc/hmm-utils.cc:465-493): trans_cost_h[tid] = -GetScaledTransitionLogProb
+ * (:442-463), added to every arc carrying that tid when khg_align runs (the resident graphs keep
+ * their base weights, as scripts/gmm_align_compiled.py:36-41 does on a copy per call).
+ * NULL resets to "no transition probs added". */
+int khg_tm_set_trans_cost(khg_tm *tm, const float *trans_cost_h);
+int khg_tm_destroy(khg_tm *tm);
+
+/* ---- utterances: features + decoding graphs, resident in HBM --------------------------- */
+/* feats: [frame_off[n_utt]][dim] float32 row-major, either host (feats_h) or already on the
+ * device (feats_d, borrowed: must outlive the handle).  Graphs: fst::VectorFst<StdArc> per
+ * utterance (the `fst` argument of python/csrc/decoder-wrappers.cc:25-47) concatenated as CSR
+ * by source state: utterance u owns states [state_off[u], state_off[u+1]); global state s owns
+ * arcs [arc_off[s], arc_off[s+1]); nextstate is utterance-local; start_h[u] = -1 for an empty
+ * FST; final_h[s] = +inf for non-final (TropicalWeight::Zero()).  Pass n_states_total = 0 and
+ * NULL graph arrays for a features-only set (log-likes / acc-stats without alignment). */
+int khg_utts_create(khg_ctx *ctx, const khg_tm *tm, int32_t n_utt, int32_t dim,
+                    const int64_t *frame_off_h, const float *feats_h, const float *feats_d,
+                    const int64_t *state_off_h, const int32_t *start_h, const int64_t *arc_off_h,
+                    const int32_t *ilabel_h, const int32_t *olabel_h, const float *weight_h,
+                    const int32_t *nextstate_h, const float *final_h, khg_utts **out);
+int khg_utts_destroy(khg_utts *u);
+/* number of distinct pdfs on each utterance's graph, and the list itself (sorted) */
+int khg_utts_num_pdfs(const khg_utts *u, int64_t *pdf_off_h /* [n_utt+1] */);
+int khg_utts_pdfs(const khg_utts *u, int32_t *pdfs_h /* [pdf_off[n_utt]] */);
+
+/* ---- K1: log-likelihoods --------------------------------------------------------------- */
+/* DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased (csrc/decodable-am-diag-gmm.cc:29-71) for
+ * every (frame, pdf on the utterance's graph); DiagGmm::LogLikelihood (csrc/diag-gmm.cc:150-165)
+ * when a pdf list is given explicitly.  Result layout per utterance: ll[j * tpad + t],
+ * tpad = T rounded up to 32, j = index into the utterance's pdf list.  KHG_E_RUNTIME if any
+ * value is NaN/Inf (the reference throws, :63-65). */
+int khg_loglikes(khg_ctx *ctx, const khg_model *m, khg_utts *u);
+/* total floats of the resident ll buffer and per-utterance offsets [n_utt+1] */
+int khg_loglikes_layout(const khg_utts *u, int64_t *ll_off_h, int64_t *total);
+int khg_loglikes_download(khg_ctx *ctx, const khg_utts *u, float *ll_h);
+/* test hook: overwrite the resident ll buffer (lets K2 be checked bit-exactly on given scores) */
+int khg_loglikes_upload(khg_ctx *ctx, khg_utts *u, const float *ll_h);
+/* features-only sets: give every utterance the same explicit pdf list */
+int khg_utts_set_pdf_list(khg_utts *u, int32_t n, const int32_t *pdfs_h);
+
+/* ---- K2: Viterbi forced alignment ------------------------------------------------------ */
+typedef struct {
+  float beam;        /* AlignConfig (csrc/decoder-wrappers.h:23-37): 200 */
+  float retry_beam;  /* 0 */
+  int32_t careful;   /* 0; graphs must have been built with khg_careful_graph by the caller */
+  float acoustic_scale;
+  /* FasterDecoderOptions (csrc/faster-decoder.h:24-49); AlignUtteranceWrapper keeps defaults */
+  int32_t max_active; /* INT32_MAX */
+  int32_t min_active; /* 20 */
+  float beam_delta;   /* 0.5 */
+  float hash_ratio;   /* 2.0 */
+} khg_align_config;
+void khg_align_config_default(khg_align_config *c);
+
+/* per-utterance status bits */
+#define KHG_ALIGN_DONE 0
+#define KHG_ALIGN_ERROR 1     /* num_error++ (empty graph / no final state reached)            */
+#define KHG_ALIGN_RETRIED 2   /* num_retried++                                                 */
+#define KHG_ALIGN_EXACT_DP 4  /* info: produced by the exact-DP kernel under a beam certificate */
+#define KHG_ALIGN_FALLBACK 8  /* info: produced by the order-faithful FasterDecoder kernel     */
+
+/* AlignUtteranceWrapper (csrc/decoder-wrappers.cc:16-108) + FasterDecoder (csrc/faster-decoder.cc)
+ * + DecodableAmDiagGmmScaled (csrc/decodable-am-diag-gmm.h:83-103) for every utterance of the
+ * set.  Requires khg_loglikes() (or khg_loglikes_upload) first.  Outputs (host, may be NULL):
+ *   ali_h[frame_off[n_utt]]  transition-ids, 0 for failed utterances
+ *   words_h / words_off_h[n_utt+1]: olabels != 0 along the best path (words_cap = capacity)
+ *   like_h[n_utt]   float `like` of decoder-wrappers.cc:95
+ *   status_h[n_utt] KHG_ALIGN_* bits.
+ * The alignment also stays resident on the device for khg_acc_stats. */
+int khg_align(khg_ctx *ctx, const khg_tm *tm, khg_utts *u, const khg_align_config *cfg,
+              int32_t *ali_h, int32_t *words_h, int64_t *words_off_h, int64_t words_cap,
+              float *like_h, int32_t *status_h);
+/* replace the resident alignment (e.g. an initial equal-align, egs/yesno/train.py:86-108) */
+int khg_ali_upload(khg_ctx *ctx, khg_utts *u, const int32_t *ali_h);
+
+/* ---- K3: sufficient statistics ---------------------------------------------------------- */
+/* AccumAmDiagGmm (csrc/mle-am-diag-gmm.h:93-96) + transition stats (csrc/transition-model.h:176-189)
+ * as ONE contiguous fp64 device buffer (a single RCCL all-reduce sums it across GPUs =
+ * AccumAmDiagGmm::Add, csrc/mle-am-diag-gmm.cc:119-128):
+ *   [ occ: sumG | mean_acc: sumG*dim | var_acc: sumG*dim | trans_acc: num_tids+1 |
+ *     total_frames, total_log_like, 6 spare ]                                                  */
+int khg_accs_create(khg_ctx *ctx, const khg_model *m, const khg_tm *tm, khg_accs **out);
+int khg_accs_destroy(khg_accs *a);
+int khg_accs_zero(khg_ctx *ctx, khg_accs *a);
+int khg_accs_size(const khg_accs *a, int64_t *num_doubles);
+int khg_accs_device_ptr(const khg_accs *a, void **ptr_d);
+int khg_accs_download(khg_ctx *ctx, const khg_accs *a, double *buf_h);
+int khg_accs_upload(khg_ctx *ctx, khg_accs *a, const double *buf_h);
+
+/* scripts/gmm_acc_stats_ali.py:46-56 for every frame of every utterance with a resident
+ * alignment: AccumAmDiagGmm::AccumulateForGmm (csrc/mle-am-diag-gmm.cc:41-52) ->
+ * AccumDiagGmm::AccumulateFromDiag/FromPosteriors (csrc/mle-diag-gmm.cc:123-158) ->
+ * DiagGmm::ComponentPosteriors (csrc/diag-gmm.cc:368-392), plus tacc[tid] += 1. */
+int khg_acc_stats(khg_ctx *ctx, const khg_model *m, const khg_tm *tm, khg_utts *u, float weight,
+                  khg_accs *a);
+
+/* ---- host-side M-step and helpers (no GPU needed) --------------------------------------- */
+/* DiagGmm::ComputeGconsts (csrc/diag-gmm.cc:103-147) for a ragged model; num_bad_out may be NULL */
+int khg_compute_gconsts(int32_t num_pdfs, int32_t dim, const int32_t *gauss_off,
+                        const float *weights, const float *inv_vars, const float *means_invvars,
+                        float *gconsts, int32_t *num_bad_out);
+
+typedef struct {
+  float min_gaussian_weight;          /* MleDiagGmmOptions (csrc/mle-diag-gmm.h:23-45): 1e-5 */
+  float min_gaussian_occupancy;       /* 10 */
+  double min_variance;                /* 1e-3 */
+  int32_t remove_low_count_gaussians; /* 1 */
+} khg_mle_options;
+void khg_mle_options_default(khg_mle_options *o);
+
+/* MleAmDiagGmmUpdate (csrc/mle-am-diag-gmm.cc:153-202) over flat arrays.  In: accumulator
+ * arrays laid out like the model (gauss_off); in/out: weights, gconsts, means_invvars, inv_vars
+ * compacted in place when Gaussians are removed; out: new_gauss_off[num_pdfs+1],
+ * objf_change, count (floats, as the reference returns them). */
+int khg_mle_am_diag_gmm_update(const khg_mle_options *o, int32_t num_pdfs, int32_t dim,
+                               const int32_t *gauss_off, const double *occ, const double *mean_acc,
+                               const double *var_acc, uint16_t acc_flags, uint16_t flags,
+                               float *weights, float *gconsts, float *means_invvars,
+                               float *inv_vars, int32_t *new_gauss_off, float *objf_change,
+                               float *count, int32_t *floored_elems, int32_t *floored_gauss,
+                               int32_t *removed);
+
+/* TransitionModel::MleUpdate (csrc/transition-model.cc:657-750) + ComputeDerivedOfProbs (:339-359) */
+int khg_transition_mle_update(int32_t num_tstates, const int32_t *state2id,
+                              const int32_t *self_loop_of, const double *stats, float floor_,
+                              float mincount, float *log_probs, float *non_self_loop_log_probs,
+                              float *objf_impr, float *count);
+
+/* GetScaledTransitionLogProb (csrc/hmm-utils.cc:442-463) negated, for every tid:
+ * out_cost[0..num_tids] (entry 0 = 0). */
+int khg_scaled_trans_cost(int32_t num_tids, const float *log_probs,
+                          const float *non_self_loop_log_probs, const int32_t *id2state,
+                          const uint8_t *is_self_loop, float transition_scale,
+                          float self_loop_scale, float *out_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KHG_HIP_H_ */

@@ -1,0 +1,689 @@
+// kaldi_hmm_gmm_amd/csrc/khg_capi.hip -- C-ABI implementation (include/khg_hip.h):
+// host-side planning (model tile image, per-utterance pdf lists, in-arc CSR, K1 chunks) and
+// the launches of K1 / K2 / K3.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/khg_hip.h"
+
+#include "khg_k1_loglikes.hip.inc"
+#include "khg_k2_viterbi.hip.inc"
+#include "khg_k3_accstats.hip.inc"
+
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+extern "C" const char* khg_last_error(void) { return g_err.c_str(); }
+int khg_set_error(int code, const std::string& msg) { g_err = msg; return code; }  // shared with khg_host.cpp
+extern "C" int khg_version(void) { return 100; }
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return khg_set_error(KHG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+struct khg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int32_t* err_flag_d = nullptr;
+};
+
+template <class T>
+static int dev_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return KHG_OK;
+}
+template <class T>
+static int dev_upload(khg_ctx* ctx, T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return KHG_OK;
+}
+#define DEVFREE(p) do { if (p) { (void)hipFree((void*)(p)); (p) = nullptr; } } while (0)
+
+extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
+  if (!out) return khg_set_error(KHG_E_ARG, "khg_ctx_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return khg_set_error(KHG_E_HIP, "khg_ctx_create: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return khg_set_error(KHG_E_ARG, "khg_ctx_create: bad device index");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return khg_set_error(KHG_E_UNSUPPORTED, std::string("khg_ctx_create: built for gfx950, device is ") + prop.gcnArchName);
+  khg_ctx* c = new khg_ctx();
+  c->device = device;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  int rc = dev_alloc(&c->err_flag_d, 1);
+  if (rc) { delete c; return rc; }
+  HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
+  *out = c;
+  return KHG_OK;
+}
+extern "C" int khg_ctx_destroy(khg_ctx* c) {
+  if (!c) return KHG_OK;
+  (void)hipStreamSynchronize(c->stream);
+  DEVFREE(c->err_flag_d);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return KHG_OK;
+}
+extern "C" int khg_ctx_sync(khg_ctx* c) {
+  if (!c) return khg_set_error(KHG_E_ARG, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KHG_OK;
+}
+// read-and-clear the device error word; maps bits to the reference's exceptions
+static int check_err_flag(khg_ctx* c, const char* where) {
+  int32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, c->err_flag_d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (f) {
+    HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
+    if (f & 1) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": Invalid answer (overflow or invalid variances/features?)");
+    if (f & 2) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": internal queue overflow in the faithful decoder");
+    return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": pdf-id out of range (graph/model mismatch)");
+  }
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+struct khg_model {
+  khg_ctx* ctx = nullptr;
+  int32_t P = 0, D = 0, KQ = 0, ntiles = 0;
+  int64_t sumG = 0;
+  std::vector<int32_t> gauss_off, pdf_tile_off;
+  float* wimg_d = nullptr;
+  int32_t* pdf_tile_off_d = nullptr;
+  int32_t* gauss_off_d = nullptr;
+  float *gconsts_d = nullptr, *miv_d = nullptr, *iv_d = nullptr;
+};
+
+extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_t* gauss_off,
+                                const float* gconsts, const float* miv, const float* iv, khg_model** out) {
+  if (!ctx || !out || P <= 0 || D <= 0 || !gauss_off || !gconsts || !miv || !iv)
+    return khg_set_error(KHG_E_ARG, "khg_model_create: bad arguments");
+  if (D > 80) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_create: feature dim > 80 is not supported by the K1 kernel yet");
+  if (gauss_off[0] != 0) return khg_set_error(KHG_E_ARG, "khg_model_create: gauss_off[0] != 0");
+  for (int p = 0; p < P; ++p)
+    if (gauss_off[p + 1] <= gauss_off[p]) return khg_set_error(KHG_E_ARG, "khg_model_create: every pdf needs >= 1 Gaussian");
+  khg_model* m = new khg_model();
+  m->ctx = ctx; m->P = P; m->D = D;
+  m->KQ = (D <= 40) ? 10 : 20;
+  m->gauss_off.assign(gauss_off, gauss_off + P + 1);
+  m->sumG = gauss_off[P];
+  m->pdf_tile_off.resize(P + 1);
+  int nt = 0;
+  for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (gauss_off[p + 1] - gauss_off[p] + 31) / 32; }
+  m->pdf_tile_off[P] = nt;
+  m->ntiles = nt;
+  // tile image: [h][32][ROW] with h=0: means_invvars, h=1: -0.5*inv_vars (exact scaling), then
+  // gconst[32]; padding rows: W = 0, gconst = -inf (contribute exp(-inf) = 0 to the log-sum-exp)
+  const int ROW = khg_row_floats(m->KQ), TILE = khg_tile_floats(m->KQ);
+  std::vector<float> img((size_t)nt * TILE, 0.0f);
+  for (int p = 0; p < P; ++p) {
+    int G = gauss_off[p + 1] - gauss_off[p];
+    for (int g = 0; g < ((G + 31) / 32) * 32; ++g) {
+      float* t = img.data() + (size_t)(m->pdf_tile_off[p] + g / 32) * TILE;
+      int r = g % 32;
+      if (g < G) {
+        const float* mi = miv + (size_t)(gauss_off[p] + g) * D;
+        const float* v = iv + (size_t)(gauss_off[p] + g) * D;
+        for (int d = 0; d < D; ++d) { t[(0 * 32 + r) * ROW + d] = mi[d]; t[(1 * 32 + r) * ROW + d] = -0.5f * v[d]; }
+        t[2 * 32 * ROW + r] = gconsts[gauss_off[p] + g];
+      } else {
+        t[2 * 32 * ROW + r] = -INFINITY;
+      }
+    }
+  }
+  int rc = dev_upload(ctx, &m->wimg_d, img);
+  if (!rc) rc = dev_upload(ctx, &m->pdf_tile_off_d, m->pdf_tile_off);
+  if (!rc) rc = dev_upload(ctx, &m->gauss_off_d, m->gauss_off);
+  std::vector<float> tmp;
+  if (!rc) { tmp.assign(gconsts, gconsts + m->sumG); rc = dev_upload(ctx, &m->gconsts_d, tmp); }
+  if (!rc) { tmp.assign(miv, miv + m->sumG * D); rc = dev_upload(ctx, &m->miv_d, tmp); }
+  if (!rc) { tmp.assign(iv, iv + m->sumG * D); rc = dev_upload(ctx, &m->iv_d, tmp); }
+  if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
+  if (rc) { khg_model_destroy(m); return rc; }
+  *out = m;
+  return KHG_OK;
+}
+extern "C" int khg_model_destroy(khg_model* m) {
+  if (!m) return KHG_OK;
+  DEVFREE(m->wimg_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d);
+  delete m;
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+struct khg_tm {
+  khg_ctx* ctx = nullptr;
+  int32_t num_tids = 0, max_pdf = -1;
+  std::vector<int32_t> id2pdf;
+  int32_t* id2pdf_d = nullptr;
+  float* trans_cost_d = nullptr;
+  bool has_trans_cost = false;
+};
+extern "C" int khg_tm_create(khg_ctx* ctx, int32_t num_tids, const int32_t* id2pdf, khg_tm** out) {
+  if (!ctx || !out || num_tids <= 0 || !id2pdf) return khg_set_error(KHG_E_ARG, "khg_tm_create: bad arguments");
+  khg_tm* t = new khg_tm();
+  t->ctx = ctx; t->num_tids = num_tids;
+  t->id2pdf.assign(id2pdf, id2pdf + num_tids + 1);
+  for (int i = 1; i <= num_tids; ++i) {
+    if (id2pdf[i] < 0) { delete t; return khg_set_error(KHG_E_ARG, "khg_tm_create: negative pdf-id"); }
+    t->max_pdf = std::max(t->max_pdf, id2pdf[i]);
+  }
+  int rc = dev_upload(ctx, &t->id2pdf_d, t->id2pdf);
+  if (!rc) rc = dev_alloc(&t->trans_cost_d, (size_t)num_tids + 1);
+  if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
+  if (rc) { khg_tm_destroy(t); return rc; }
+  *out = t;
+  return KHG_OK;
+}
+extern "C" int khg_tm_set_trans_cost(khg_tm* t, const float* cost) {
+  if (!t) return khg_set_error(KHG_E_ARG, "tm is NULL");
+  if (!cost) { t->has_trans_cost = false; return KHG_OK; }
+  HIPCHK(hipMemcpyAsync(t->trans_cost_d, cost, sizeof(float) * ((size_t)t->num_tids + 1), hipMemcpyHostToDevice, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  t->has_trans_cost = true;
+  return KHG_OK;
+}
+extern "C" int khg_tm_destroy(khg_tm* t) {
+  if (!t) return KHG_OK;
+  DEVFREE(t->id2pdf_d); DEVFREE(t->trans_cost_d);
+  delete t;
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+struct khg_utts {
+  khg_ctx* ctx = nullptr;
+  int32_t n_utt = 0, D = 0;
+  int64_t N = 0;  // total frames
+  bool has_graphs = false;
+  std::vector<int64_t> frame_off, state_off, pdf_off, ll_off, bp_off, path_off, words_off;
+  std::vector<int32_t> pdfs;
+  int32_t max_states = 0, max_inarcs = 0;
+  // device
+  const float* feats_d = nullptr; bool own_feats = false;
+  int64_t *frame_off_d = nullptr, *state_off_d = nullptr, *pdf_off_d = nullptr, *ll_off_d = nullptr;
+  int32_t *pdfs_d = nullptr, *start_d = nullptr;
+  int64_t *in_off_d = nullptr, *out_off_d = nullptr;
+  int32_t *in_src_d = nullptr, *in_col_d = nullptr, *in_tid_d = nullptr, *in_olabel_d = nullptr, *out_inidx_d = nullptr;
+  float *in_w_d = nullptr, *final_d = nullptr;
+  // K1
+  K1Chunk* chunks_d = nullptr; int32_t n_chunks = 0; int32_t chunk_kq = 0;
+  float* ll_d = nullptr; int64_t ll_total = 0; bool ll_valid = false;
+  // K2 scratch / outputs
+  uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
+  double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
+  int32_t *ali_d = nullptr, *words_d = nullptr, *num_words_d = nullptr, *status_d = nullptr;
+  float* like_d = nullptr;
+  bool ali_valid = false;
+  // K3 scratch
+  int32_t *pdf_count_d = nullptr, *pdf_cursor_d = nullptr, *frame_ids_d = nullptr;
+  int64_t* pdf_start_d = nullptr; unsigned long long* tid_count_d = nullptr;
+  int32_t k3_P = 0, k3_tids = 0;
+};
+
+static void plan_ll(khg_utts* u) {
+  u->ll_off.assign(u->n_utt + 1, 0);
+  for (int i = 0; i < u->n_utt; ++i) {
+    int64_t T = u->frame_off[i + 1] - u->frame_off[i];
+    int64_t tpad = (T + 31) & ~int64_t(31);
+    u->ll_off[i + 1] = u->ll_off[i] + (u->pdf_off[i + 1] - u->pdf_off[i]) * tpad;
+  }
+  u->ll_total = u->ll_off[u->n_utt];
+}
+
+extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, int32_t D,
+                               const int64_t* frame_off, const float* feats_h, const float* feats_dv,
+                               const int64_t* state_off, const int32_t* start, const int64_t* arc_off,
+                               const int32_t* ilabel, const int32_t* olabel, const float* weight,
+                               const int32_t* nextstate, const float* final_w, khg_utts** out) {
+  if (!ctx || !out || n_utt <= 0 || D <= 0 || !frame_off || (!feats_h && !feats_dv))
+    return khg_set_error(KHG_E_ARG, "khg_utts_create: bad arguments");
+  if (frame_off[0] != 0) return khg_set_error(KHG_E_ARG, "khg_utts_create: frame_off[0] != 0");
+  for (int i = 0; i < n_utt; ++i)
+    if (frame_off[i + 1] < frame_off[i]) return khg_set_error(KHG_E_ARG, "khg_utts_create: frame_off not monotone");
+  khg_utts* u = new khg_utts();
+  u->ctx = ctx; u->n_utt = n_utt; u->D = D;
+  u->frame_off.assign(frame_off, frame_off + n_utt + 1);
+  u->N = frame_off[n_utt];
+  int rc = KHG_OK;
+  auto fail = [&](int code, const std::string& msg) { khg_utts_destroy(u); return khg_set_error(code, msg); };
+  if (feats_dv) { u->feats_d = feats_dv; u->own_feats = false; }
+  else {
+    float* p = nullptr;
+    rc = dev_alloc(&p, (size_t)u->N * D);
+    if (rc) { khg_utts_destroy(u); return rc; }
+    u->feats_d = p; u->own_feats = true;
+    if (u->N) {
+      hipError_t e = hipMemcpyAsync(p, feats_h, sizeof(float) * (size_t)u->N * D, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) return fail(KHG_E_HIP, hipGetErrorString(e));
+    }
+  }
+  rc = dev_upload(ctx, &u->frame_off_d, u->frame_off);
+  if (rc) { khg_utts_destroy(u); return rc; }
+  u->pdf_off.assign(n_utt + 1, 0);
+
+  if (state_off && state_off[n_utt] > 0) {
+    if (!tm || !start || !arc_off || !ilabel || !olabel || !weight || !nextstate || !final_w)
+      return fail(KHG_E_ARG, "khg_utts_create: graph arrays / tm missing");
+    u->has_graphs = true;
+    u->state_off.assign(state_off, state_off + n_utt + 1);
+    const int64_t NS = state_off[n_utt], NA = arc_off[NS];
+    std::vector<int64_t> in_off(NS + 1, 0), out_off(arc_off, arc_off + NS + 1);
+    std::vector<int32_t> in_src(NA), in_col(NA), in_tid(NA), in_ol(NA), out_inidx(NA);
+    std::vector<float> in_w(NA);
+    std::vector<int32_t> tmp_pdfs, cursor;
+    u->bp_off.assign(n_utt + 1, 0); u->path_off.assign(n_utt + 1, 0); u->words_off.assign(n_utt + 1, 0);
+    for (int i = 0; i < n_utt; ++i) {
+      const int64_t s0 = state_off[i], S = state_off[i + 1] - s0;
+      const int64_t a0 = arc_off[s0], a1 = arc_off[s0 + S], A = a1 - a0;
+      const int64_t T = frame_off[i + 1] - frame_off[i];
+      if (S < 0 || A < 0) return fail(KHG_E_ARG, "khg_utts_create: offsets not monotone");
+      if (start[i] >= S) return fail(KHG_E_ARG, "khg_utts_create: start state out of range");
+      u->max_states = std::max<int64_t>(u->max_states, S);
+      u->max_inarcs = std::max<int64_t>(u->max_inarcs, A);
+      // pdf list of this utterance = distinct id2pdf[ilabel] over its arcs
+      tmp_pdfs.clear();
+      int64_t nwords = 0;
+      for (int64_t a = a0; a < a1; ++a) {
+        int l = ilabel[a];
+        if (l < 0 || l > tm->num_tids)
+          return fail(KHG_E_RUNTIME, "AddTransitionProbs: invalid symbol " + std::to_string(l) + " on graph input side.");
+        if (l >= 1) tmp_pdfs.push_back(tm->id2pdf[l]);
+        if (nextstate[a] < 0 || nextstate[a] >= S) return fail(KHG_E_ARG, "khg_utts_create: nextstate out of range");
+        if (olabel[a] != 0) ++nwords;
+      }
+      std::sort(tmp_pdfs.begin(), tmp_pdfs.end());
+      tmp_pdfs.erase(std::unique(tmp_pdfs.begin(), tmp_pdfs.end()), tmp_pdfs.end());
+      u->pdf_off[i + 1] = u->pdf_off[i] + (int64_t)tmp_pdfs.size();
+      u->pdfs.insert(u->pdfs.end(), tmp_pdfs.begin(), tmp_pdfs.end());
+      // in-arc CSR: stable bucketing by destination (ties in the DP then resolve to the lowest
+      // original arc index, like a strict '<' scan over arcs in file order)
+      for (int64_t a = a0; a < a1; ++a) in_off[s0 + nextstate[a] + 1]++;
+      in_off[s0] = a0;
+      for (int64_t s = 0; s < S; ++s) {
+        if (in_off[s0 + s + 1] > 254) return fail(KHG_E_UNSUPPORTED, "khg_utts_create: a state has more than 254 incoming arcs");
+        in_off[s0 + s + 1] += in_off[s0 + s];
+      }
+      cursor.assign(S, 0);
+      for (int64_t s = 0; s < S; ++s) {
+        for (int64_t a = arc_off[s0 + s]; a < arc_off[s0 + s + 1]; ++a) {
+          int d = nextstate[a];
+          int64_t pos = in_off[s0 + d] + cursor[d]++;
+          in_src[pos] = (int32_t)s;
+          in_tid[pos] = ilabel[a];
+          in_ol[pos] = olabel[a];
+          in_w[pos] = weight[a];
+          int col = -1;
+          if (ilabel[a] >= 1)
+            col = (int)(std::lower_bound(tmp_pdfs.begin(), tmp_pdfs.end(), tm->id2pdf[ilabel[a]]) - tmp_pdfs.begin());
+          in_col[pos] = col;
+          out_inidx[a] = (int32_t)(pos - a0);
+        }
+      }
+      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * S;
+      u->path_off[i + 1] = u->path_off[i] + T + S + 8;
+      u->words_off[i + 1] = u->words_off[i] + nwords;
+    }
+    in_off[NS] = NA;
+    std::vector<int32_t> startv(start, start + n_utt);
+    std::vector<float> finalv(final_w, final_w + NS);
+    rc = dev_upload(ctx, &u->state_off_d, u->state_off);
+    if (!rc) rc = dev_upload(ctx, &u->start_d, startv);
+    if (!rc) rc = dev_upload(ctx, &u->in_off_d, in_off);
+    if (!rc) rc = dev_upload(ctx, &u->out_off_d, out_off);
+    if (!rc) rc = dev_upload(ctx, &u->in_src_d, in_src);
+    if (!rc) rc = dev_upload(ctx, &u->in_col_d, in_col);
+    if (!rc) rc = dev_upload(ctx, &u->in_tid_d, in_tid);
+    if (!rc) rc = dev_upload(ctx, &u->in_olabel_d, in_ol);
+    if (!rc) rc = dev_upload(ctx, &u->out_inidx_d, out_inidx);
+    if (!rc) rc = dev_upload(ctx, &u->in_w_d, in_w);
+    if (!rc) rc = dev_upload(ctx, &u->final_d, finalv);
+    if (!rc) rc = dev_upload(ctx, &u->bp_off_d, u->bp_off);
+    if (!rc) rc = dev_upload(ctx, &u->path_off_d, u->path_off);
+    if (!rc) rc = dev_upload(ctx, &u->words_off_d, u->words_off);
+    if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
+    if (rc) { khg_utts_destroy(u); return rc; }
+  }
+  plan_ll(u);
+  { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return fail(KHG_E_HIP, hipGetErrorString(e)); }
+  *out = u;
+  return KHG_OK;
+}
+
+extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs) {
+  if (!u || n <= 0 || !pdfs) return khg_set_error(KHG_E_ARG, "khg_utts_set_pdf_list: bad arguments");
+  if (u->has_graphs) return khg_set_error(KHG_E_ARG, "khg_utts_set_pdf_list: set has graphs; its pdf lists come from them");
+  u->pdfs.clear();
+  for (int i = 0; i < u->n_utt; ++i) { u->pdf_off[i + 1] = u->pdf_off[i] + n; u->pdfs.insert(u->pdfs.end(), pdfs, pdfs + n); }
+  plan_ll(u);
+  DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d);
+  u->ll_valid = false;
+  return KHG_OK;
+}
+
+extern "C" int khg_utts_destroy(khg_utts* u) {
+  if (!u) return KHG_OK;
+  if (u->own_feats) DEVFREE(u->feats_d);
+  DEVFREE(u->frame_off_d); DEVFREE(u->state_off_d); DEVFREE(u->pdf_off_d); DEVFREE(u->ll_off_d);
+  DEVFREE(u->pdfs_d); DEVFREE(u->start_d); DEVFREE(u->in_off_d); DEVFREE(u->out_off_d);
+  DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
+  DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d);
+  DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
+  DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
+  DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
+  DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
+  delete u;
+  return KHG_OK;
+}
+extern "C" int khg_utts_num_pdfs(const khg_utts* u, int64_t* pdf_off) {
+  if (!u || !pdf_off) return khg_set_error(KHG_E_ARG, "bad arguments");
+  std::copy(u->pdf_off.begin(), u->pdf_off.end(), pdf_off);
+  return KHG_OK;
+}
+extern "C" int khg_utts_pdfs(const khg_utts* u, int32_t* pdfs) {
+  if (!u || !pdfs) return khg_set_error(KHG_E_ARG, "bad arguments");
+  std::copy(u->pdfs.begin(), u->pdfs.end(), pdfs);
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1
+template <int KQ, int NF, int WPS>
+static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s) {
+  if (aligned) hipLaunchKernelGGL((k1_loglikes<KQ, NF, true, WPS>), dim3(nchunks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
+}
+static constexpr int k1_nf(int KQ) { return KQ == 10 ? 3 : 4; }
+
+extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
+  if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
+  if (m->D != u->D) return khg_set_error(KHG_E_RUNTIME, "Dim mismatch: data dim = " + std::to_string(u->D) + " vs. model dim = " + std::to_string(m->D));
+  for (int32_t p : u->pdfs)
+    if (p < 0 || p >= m->P) return khg_set_error(KHG_E_RUNTIME, "Likely graph/model mismatch, e.g. using wrong HCLG.fst (pdf-id " + std::to_string(p) + ")");
+  int rc = KHG_OK;
+  if (!u->pdf_off_d) {
+    rc = dev_upload(ctx, &u->pdf_off_d, u->pdf_off);
+    if (!rc) rc = dev_upload(ctx, &u->pdfs_d, u->pdfs);
+    if (!rc) rc = dev_upload(ctx, &u->ll_off_d, u->ll_off);
+    if (!rc) rc = dev_alloc(&u->ll_d, (size_t)u->ll_total);
+    if (rc) return rc;
+  }
+  if (!u->chunks_d || u->chunk_kq != m->KQ) {
+    DEVFREE(u->chunks_d);
+    const int maxtiles = 4 * k1_nf(m->KQ);
+    std::vector<K1Chunk> ch;
+    for (int i = 0; i < u->n_utt; ++i) {
+      int64_t T = u->frame_off[i + 1] - u->frame_off[i];
+      if (T <= 0 || u->pdf_off[i + 1] == u->pdf_off[i]) continue;
+      int n32 = (int)((T + 31) / 32);
+      int nchunks = (n32 + maxtiles - 1) / maxtiles;
+      int per = (n32 + nchunks - 1) / nchunks;
+      for (int c = 0; c < nchunks; ++c) {
+        int t0 = c * per * 32;
+        int nfr = (int)std::min<int64_t>((int64_t)per * 32, T - t0);
+        if (nfr <= 0) break;
+        ch.push_back(K1Chunk{i, t0, nfr, 0});
+      }
+    }
+    u->n_chunks = (int)ch.size();
+    u->chunk_kq = m->KQ;
+    rc = dev_upload(ctx, &u->chunks_d, ch);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
+  }
+  K1Args a;
+  a.feats = u->feats_d; a.frame_off = u->frame_off_d; a.chunks = u->chunks_d; a.wimg = m->wimg_d;
+  a.pdf_tile_off = m->pdf_tile_off_d; a.utt_pdf_off = u->pdf_off_d; a.utt_pdfs = u->pdfs_d;
+  a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d; a.D = m->D;
+  const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
+  if (u->n_chunks > 0) {
+    if (m->KQ == 10) launch_k1<10, 3, 2>(a, u->n_chunks, aligned, ctx->stream);
+    else launch_k1<20, 4, 1>(a, u->n_chunks, aligned, ctx->stream);
+    HIPCHK(hipGetLastError());
+  }
+  u->ll_valid = true;
+  return KHG_OK;
+}
+extern "C" int khg_loglikes_layout(const khg_utts* u, int64_t* ll_off, int64_t* total) {
+  if (!u) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ll_off) std::copy(u->ll_off.begin(), u->ll_off.end(), ll_off);
+  if (total) *total = u->ll_total;
+  return KHG_OK;
+}
+extern "C" int khg_loglikes_download(khg_ctx* ctx, const khg_utts* u, float* ll) {
+  if (!ctx || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (!u->ll_valid) return khg_set_error(KHG_E_ARG, "khg_loglikes_download: call khg_loglikes first");
+  int rc = check_err_flag(ctx, "khg_loglikes");
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ll, u->ll_d, sizeof(float) * (size_t)u->ll_total, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
+  if (!ctx || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
+  int rc = KHG_OK;
+  if (!u->pdf_off_d) {
+    rc = dev_upload(ctx, &u->pdf_off_d, u->pdf_off);
+    if (!rc) rc = dev_upload(ctx, &u->pdfs_d, u->pdfs);
+    if (!rc) rc = dev_upload(ctx, &u->ll_off_d, u->ll_off);
+    if (!rc) rc = dev_alloc(&u->ll_d, (size_t)u->ll_total);
+    if (rc) return rc;
+  }
+  HIPCHK(hipMemcpyAsync(u->ll_d, ll, sizeof(float) * (size_t)u->ll_total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  u->ll_valid = true;
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2
+extern "C" void khg_align_config_default(khg_align_config* c) {
+  c->beam = 200.0f; c->retry_beam = 0.0f; c->careful = 0; c->acoustic_scale = 1.0f;
+  c->max_active = INT32_MAX; c->min_active = 20; c->beam_delta = 0.5f; c->hash_ratio = 2.0f;
+}
+
+static int ensure_ali(khg_ctx* ctx, khg_utts* u) {
+  if (!u->ali_d) { int rc = dev_alloc(&u->ali_d, (size_t)u->N); if (rc) return rc; }
+  return KHG_OK;
+}
+
+extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_align_config* cfg,
+                         int32_t* ali_h, int32_t* words_h, int64_t* words_off_h, int64_t words_cap,
+                         float* like_h, int32_t* status_h) {
+  if (!ctx || !tm || !u || !cfg) return khg_set_error(KHG_E_ARG, "khg_align: bad arguments");
+  if (!u->has_graphs) return khg_set_error(KHG_E_ARG, "khg_align: the utterance set has no decoding graphs");
+  if (!u->ll_valid) return khg_set_error(KHG_E_ARG, "khg_align: call khg_loglikes first");
+  // decoder-wrappers.cc:29-33
+  if ((cfg->retry_beam != 0 && cfg->retry_beam <= cfg->beam) || cfg->beam <= 0.0)
+    return khg_set_error(KHG_E_RUNTIME, "Beams do not make sense: beam " + std::to_string(cfg->beam) + ", retry-beam " + std::to_string(cfg->retry_beam));
+  // faster-decoder.cc:24-27
+  if (!(cfg->hash_ratio >= 1.0) || !(cfg->max_active > 1) || !(cfg->min_active >= 0 && cfg->min_active < cfg->max_active))
+    return khg_set_error(KHG_E_RUNTIME, "FasterDecoderOptions assertion failed");
+  int rc = ensure_ali(ctx, u);
+  if (rc) return rc;
+  if (!u->bp_d) {
+    rc = dev_alloc(&u->bp_d, (size_t)u->bp_off[u->n_utt]);
+    if (!rc) rc = dev_alloc(&u->layer_best_d, (size_t)(u->N + u->n_utt));
+    if (!rc) rc = dev_alloc(&u->layer_cnt_d, (size_t)(u->N + u->n_utt));
+    if (!rc) rc = dev_alloc(&u->path_d, (size_t)u->path_off[u->n_utt]);
+    if (!rc) rc = dev_alloc(&u->words_d, (size_t)u->words_off[u->n_utt]);
+    if (!rc) rc = dev_alloc(&u->num_words_d, (size_t)u->n_utt);
+    if (!rc) rc = dev_alloc(&u->status_d, (size_t)u->n_utt);
+    if (!rc) rc = dev_alloc(&u->like_d, (size_t)u->n_utt);
+    if (rc) return rc;
+  }
+  HIPCHK(hipMemsetAsync(u->ali_d, 0, sizeof(int32_t) * (size_t)u->N, ctx->stream));
+  K2Args a;
+  a.frame_off = u->frame_off_d; a.state_off = u->state_off_d; a.start = u->start_d;
+  a.in_off = u->in_off_d; a.in_src = u->in_src_d; a.in_col = u->in_col_d; a.in_tid = u->in_tid_d;
+  a.in_olabel = u->in_olabel_d; a.in_w = u->in_w_d; a.out_off = u->out_off_d; a.out_inidx = u->out_inidx_d;
+  a.final_w = u->final_d; a.trans_cost = tm->has_trans_cost ? tm->trans_cost_d : nullptr;
+  a.ll = u->ll_d; a.ll_off = u->ll_off_d;
+  a.bp = u->bp_d; a.bp_off = u->bp_off_d; a.layer_best = u->layer_best_d; a.layer_cnt = u->layer_cnt_d;
+  a.path = u->path_d; a.path_off = u->path_off_d;
+  a.ali = u->ali_d; a.words = u->words_d; a.words_off = u->words_off_d; a.num_words = u->num_words_d;
+  a.like = u->like_d; a.status = u->status_d; a.err_flag = ctx->err_flag_d;
+  a.beam = cfg->beam; a.retry_beam = cfg->retry_beam; a.acoustic_scale = cfg->acoustic_scale;
+  a.beam_delta = cfg->beam_delta; a.hash_ratio = cfg->hash_ratio;
+  a.max_active = cfg->max_active; a.min_active = cfg->min_active;
+  a.max_states = u->max_states; a.max_inarcs = u->max_inarcs;
+  const size_t S = (size_t)u->max_states, A = (size_t)u->max_inarcs;
+  size_t lds_dp = 16 * S + 16 + 4 * (S + 1) + 12 * A + 16 + 64;
+  size_t HB = std::max<size_t>(2 * S, 1000);
+  size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
+  if (lds_dp > 160 * 1024 || lds_f > 160 * 1024)
+    return khg_set_error(KHG_E_UNSUPPORTED, "khg_align: decoding graph too large for the LDS-resident Viterbi kernels (" +
+                                                std::to_string(u->max_states) + " states, " + std::to_string(u->max_inarcs) + " arcs)");
+  if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
+  if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+  const int nthr = S <= 256 ? 64 : (S <= 512 ? 128 : 256);
+  hipLaunchKernelGGL(k2_viterbi_dp, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  u->ali_valid = true;
+  rc = check_err_flag(ctx, "khg_align");  // synchronises
+  if (rc) return rc;
+  if (ali_h) HIPCHK(hipMemcpyAsync(ali_h, u->ali_d, sizeof(int32_t) * (size_t)u->N, hipMemcpyDeviceToHost, ctx->stream));
+  if (like_h) HIPCHK(hipMemcpyAsync(like_h, u->like_d, sizeof(float) * (size_t)u->n_utt, hipMemcpyDeviceToHost, ctx->stream));
+  if (status_h) HIPCHK(hipMemcpyAsync(status_h, u->status_d, sizeof(int32_t) * (size_t)u->n_utt, hipMemcpyDeviceToHost, ctx->stream));
+  if (words_h && words_off_h) {
+    std::vector<int32_t> w((size_t)u->words_off[u->n_utt]), nw((size_t)u->n_utt);
+    if (!w.empty()) HIPCHK(hipMemcpyAsync(w.data(), u->words_d, sizeof(int32_t) * w.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nw.data(), u->num_words_d, sizeof(int32_t) * nw.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int64_t o = 0;
+    for (int i = 0; i < u->n_utt; ++i) {
+      words_off_h[i] = o;
+      int64_t n = std::min<int64_t>(nw[i], u->words_off[i + 1] - u->words_off[i]);
+      if (o + n > words_cap) return khg_set_error(KHG_E_ARG, "khg_align: words_cap too small");
+      std::copy(w.begin() + u->words_off[i], w.begin() + u->words_off[i] + n, words_h + o);
+      o += n;
+    }
+    words_off_h[u->n_utt] = o;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+
+extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
+  if (!ctx || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
+  int rc = ensure_ali(ctx, u);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(u->ali_d, ali, sizeof(int32_t) * (size_t)u->N, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  u->ali_valid = true;
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// accumulators + K3
+struct khg_accs {
+  khg_ctx* ctx = nullptr;
+  int64_t sumG = 0; int32_t D = 0, num_tids = 0;
+  int64_t n = 0;
+  double* buf_d = nullptr;
+  double* occ() const { return buf_d; }
+  double* mean() const { return buf_d + sumG; }
+  double* var() const { return buf_d + sumG + sumG * D; }
+  double* trans() const { return buf_d + sumG + 2 * sumG * D; }
+  double* scalars() const { return trans() + num_tids + 1; }
+};
+extern "C" int khg_accs_create(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_accs** out) {
+  if (!ctx || !m || !tm || !out) return khg_set_error(KHG_E_ARG, "khg_accs_create: bad arguments");
+  khg_accs* a = new khg_accs();
+  a->ctx = ctx; a->sumG = m->sumG; a->D = m->D; a->num_tids = tm->num_tids;
+  a->n = a->sumG * (1 + 2 * (int64_t)a->D) + a->num_tids + 1 + 8;
+  int rc = dev_alloc(&a->buf_d, (size_t)a->n);
+  if (rc) { delete a; return rc; }
+  *out = a;
+  return khg_accs_zero(ctx, a);
+}
+extern "C" int khg_accs_destroy(khg_accs* a) { if (a) { DEVFREE(a->buf_d); delete a; } return KHG_OK; }
+extern "C" int khg_accs_zero(khg_ctx* ctx, khg_accs* a) {
+  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipMemsetAsync(a->buf_d, 0, sizeof(double) * (size_t)a->n, ctx->stream));
+  return KHG_OK;
+}
+extern "C" int khg_accs_size(const khg_accs* a, int64_t* n) { if (!a || !n) return khg_set_error(KHG_E_ARG, "bad arguments"); *n = a->n; return KHG_OK; }
+extern "C" int khg_accs_device_ptr(const khg_accs* a, void** p) { if (!a || !p) return khg_set_error(KHG_E_ARG, "bad arguments"); *p = a->buf_d; return KHG_OK; }
+extern "C" int khg_accs_download(khg_ctx* ctx, const khg_accs* a, double* buf) {
+  if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipMemcpyAsync(buf, a->buf_d, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+extern "C" int khg_accs_upload(khg_ctx* ctx, khg_accs* a, const double* buf) {
+  if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipMemcpyAsync(a->buf_d, buf, sizeof(double) * (size_t)a->n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+
+extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc) {
+  if (!ctx || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
+  if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
+  if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
+    return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");
+  if (tm->max_pdf >= m->P) return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: transition model refers to pdf-ids the model does not have");
+  int rc = KHG_OK;
+  if (!u->frame_ids_d || u->k3_P != m->P || u->k3_tids != tm->num_tids) {
+    DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d); DEVFREE(u->frame_ids_d);
+    rc = dev_alloc(&u->pdf_count_d, (size_t)m->P);
+    if (!rc) rc = dev_alloc(&u->pdf_cursor_d, (size_t)m->P);
+    if (!rc) rc = dev_alloc(&u->pdf_start_d, (size_t)m->P + 1);
+    if (!rc) rc = dev_alloc(&u->tid_count_d, (size_t)tm->num_tids + 1);
+    if (!rc) rc = dev_alloc(&u->frame_ids_d, (size_t)u->N);
+    if (rc) return rc;
+    u->k3_P = m->P; u->k3_tids = tm->num_tids;
+  }
+  HIPCHK(hipMemsetAsync(u->pdf_count_d, 0, sizeof(int32_t) * (size_t)m->P, ctx->stream));
+  HIPCHK(hipMemsetAsync(u->tid_count_d, 0, sizeof(unsigned long long) * ((size_t)tm->num_tids + 1), ctx->stream));
+  K3Args a;
+  a.feats = u->feats_d; a.ali = u->ali_d; a.id2pdf = tm->id2pdf_d; a.num_tids = tm->num_tids;
+  a.N = u->N; a.P = m->P; a.D = m->D;
+  a.gauss_off = m->gauss_off_d; a.gconsts = m->gconsts_d; a.means_invvars = m->miv_d; a.inv_vars = m->iv_d;
+  a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
+  a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
+  a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
+  a.weight = weight; a.err_flag = ctx->err_flag_d;
+  if (u->N > 0) {
+    const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
+    hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+    int maxG = 0;
+    for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
+    const int Gp = (maxG + 63) & ~63;
+    const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)m->D + Gp);
+    if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
+    const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
+    hipLaunchKernelGGL(k3_accumulate, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  return check_err_flag(ctx, "khg_acc_stats");
+}

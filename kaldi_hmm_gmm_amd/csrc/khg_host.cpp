@@ -1,0 +1,264 @@
+// kaldi_hmm_gmm_amd/csrc/khg_host.cpp -- host-side (no GPU) entry points of include/khg_hip.h:
+// gconsts, the M-step and the transition-model update.  The reference keeps these on the host
+// too (O(P*G*D) once per EM iteration); they run on the all-reduced accumulators.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/khg_hip.h"
+
+int khg_set_error(int code, const std::string& msg);  // khg_capi.hip
+
+namespace {
+
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;  // M_LOG_2PI, csrc/kaldi-math.h
+constexpr uint16_t kMeans = 0x1, kVars = 0x2, kWeights = 0x4;  // csrc/model-common.h:18-26
+
+// csrc/diag-gmm.cc:103-147 for one DiagGmm.  Returns false on NaN (the reference throws).
+bool ComputeGconstsOne(int G, int D, const float* w, const float* iv, const float* miv, float* gc_out, int* num_bad) {
+  const float offset = -0.5 * kLog2Pi * D;
+  for (int mix = 0; mix < G; ++mix) {
+    float gc = std::log(w[mix]) + offset;
+    const float* ivr = iv + (size_t)mix * D;
+    const float* mir = miv + (size_t)mix * D;
+    for (int d = 0; d < D; ++d)  // double right-hand side, float accumulator (diag-gmm.cc:121-123)
+      gc += 0.5 * std::log(ivr[d]) - 0.5 * mir[d] * mir[d] / ivr[d];
+    if (std::isnan(gc)) return false;
+    if (std::isinf(gc)) { ++*num_bad; if (gc > 0) gc = -gc; }
+    gc_out[mix] = gc;
+  }
+  return true;
+}
+
+// csrc/mle-diag-gmm.cc:479-499
+float MlObjective(int G, int D, const float* gc, const float* miv, const float* iv, const double* occ,
+                  const double* macc, const double* vacc, uint16_t acc_flags) {
+  double dot = 0.0;
+  for (int g = 0; g < G; ++g) dot += occ[g] * static_cast<double>(gc[g]);
+  float obj = dot;
+  const size_t n = (size_t)G * D;
+  if (acc_flags & kMeans) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += macc[i] * static_cast<double>(miv[i]);
+    obj += s;
+  }
+  if (acc_flags & kVars) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += vacc[i] * static_cast<double>(iv[i]);
+    obj -= 0.5 * s;
+  }
+  return obj;
+}
+
+struct UpdateResult { float obj_change = 0, count = 0; int floored_elems = 0, floored_gauss = 0, removed = 0; };
+
+// csrc/mle-diag-gmm.cc:243-390 MleDiagGmmUpdate on one pdf held in vectors (may shrink).
+bool MleUpdateOne(const khg_mle_options& o, int D, const double* occ, const double* macc, const double* vacc,
+                  uint16_t acc_flags, uint16_t flags, std::vector<float>& w, std::vector<float>& gc,
+                  std::vector<float>& miv, std::vector<float>& iv, UpdateResult* res) {
+  int G = (int)w.size();
+  const size_t n = (size_t)G * D;
+  double occ_sum = 0.0;
+  for (int g = 0; g < G; ++g) occ_sum += occ[g];
+  int nb = 0;
+  if (!ComputeGconstsOne(G, D, w.data(), iv.data(), miv.data(), gc.data(), &nb)) return false;
+  const float obj_old = MlObjective(G, D, gc.data(), miv.data(), iv.data(), occ, macc, vacc, acc_flags);
+  // DiagGmmNormal (csrc/diag-gmm-normal.cc:14-20)
+  std::vector<double> nw(G), nvars(n), nmeans(n), oldmeans;
+  for (int g = 0; g < G; ++g) nw[g] = w[g];
+  for (size_t i = 0; i < n; ++i) { nvars[i] = 1.0 / static_cast<double>(iv[i]); nmeans[i] = static_cast<double>(miv[i]) * nvars[i]; }
+  oldmeans = nmeans;
+  std::vector<int> to_remove;
+  std::vector<double> var(D), old_mean(D);
+  for (int i = 0; i < G; ++i) {
+    const double oc = occ[i];
+    const double prob = occ_sum > 0.0 ? oc / occ_sum : 1.0 / G;
+    if (oc > o.min_gaussian_occupancy && prob > o.min_gaussian_weight) {
+      nw[i] = prob;
+      double* mu = &nmeans[(size_t)i * D];
+      for (int d = 0; d < D; ++d) old_mean[d] = mu[d];
+      if (acc_flags & (kMeans | kVars))
+        for (int d = 0; d < D; ++d) mu[d] = macc[(size_t)i * D + d] / oc;
+      if (acc_flags & kVars) {
+        for (int d = 0; d < D; ++d) var[d] = vacc[(size_t)i * D + d] / oc - mu[d] * mu[d];
+        if (!(flags & kMeans))
+          for (int d = 0; d < D; ++d) { const double dm = old_mean[d] - mu[d]; var[d] += dm * dm; }
+        int floored = 0;
+        for (int d = 0; d < D; ++d)
+          if (var[d] < o.min_variance) { var[d] = o.min_variance; ++floored; }
+        if (floored) { res->floored_elems += floored; ++res->floored_gauss; }
+        for (int d = 0; d < D; ++d) nvars[(size_t)i * D + d] = var[d];
+      }
+    } else if (o.remove_low_count_gaussians && (int)to_remove.size() < G - 1) {
+      to_remove.push_back(i);
+    } else {
+      nw[i] = std::max(prob, static_cast<double>(o.min_gaussian_weight));
+    }
+  }
+  // CopyToDiagGmm (csrc/diag-gmm-normal.cc:22-48)
+  if (flags & kWeights) for (int g = 0; g < G; ++g) w[g] = static_cast<float>(nw[g]);
+  if (flags & kVars) {
+    for (size_t i = 0; i < n; ++i) iv[i] = static_cast<float>(1.0 / nvars[i]);
+    if (!(flags & kMeans)) for (size_t i = 0; i < n; ++i) miv[i] = static_cast<float>(oldmeans[i]) * iv[i];
+  }
+  if (flags & kMeans) for (size_t i = 0; i < n; ++i) miv[i] = static_cast<float>(nmeans[i]) * iv[i];
+  if (!ComputeGconstsOne(G, D, w.data(), iv.data(), miv.data(), gc.data(), &nb)) return false;
+  const float obj_new = MlObjective(G, D, gc.data(), miv.data(), iv.data(), occ, macc, vacc, acc_flags);
+  res->obj_change = obj_new - obj_old;
+  res->count = occ_sum;
+  res->removed = (int)to_remove.size();
+  if (!to_remove.empty()) {
+    // DiagGmm::RemoveComponents(to_remove, renorm=true) (csrc/diag-gmm.cc:853-938): one at a
+    // time, weights renormalised (float) after every removal
+    for (size_t r = 0; r < to_remove.size(); ++r) {
+      const int gi = to_remove[r] - (int)r;
+      w.erase(w.begin() + gi);
+      gc.erase(gc.begin() + gi);
+      miv.erase(miv.begin() + (size_t)gi * D, miv.begin() + (size_t)(gi + 1) * D);
+      iv.erase(iv.begin() + (size_t)gi * D, iv.begin() + (size_t)(gi + 1) * D);
+      float s = 0.0f;
+      for (float x : w) s += x;
+      for (float& x : w) x /= s;
+    }
+    G = (int)w.size();
+    if (!ComputeGconstsOne(G, D, w.data(), iv.data(), miv.data(), gc.data(), &nb)) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" void khg_mle_options_default(khg_mle_options* o) {
+  o->min_gaussian_weight = 1.0e-05f; o->min_gaussian_occupancy = 10.0f; o->min_variance = 0.001; o->remove_low_count_gaussians = 1;
+}
+
+extern "C" int khg_compute_gconsts(int32_t P, int32_t D, const int32_t* gauss_off, const float* weights,
+                                   const float* inv_vars, const float* means_invvars, float* gconsts, int32_t* num_bad_out) {
+  if (P <= 0 || D <= 0 || !gauss_off || !weights || !inv_vars || !means_invvars || !gconsts)
+    return khg_set_error(KHG_E_ARG, "khg_compute_gconsts: bad arguments");
+  int nb = 0;
+  for (int p = 0; p < P; ++p) {
+    const int g0 = gauss_off[p], G = gauss_off[p + 1] - g0;
+    for (int g = 0; g < G; ++g)
+      if (!(weights[g0 + g] >= 0)) return khg_set_error(KHG_E_RUNTIME, "ComputeGconsts: negative weight");  // :114
+    if (!ComputeGconstsOne(G, D, weights + g0, inv_vars + (size_t)g0 * D, means_invvars + (size_t)g0 * D, gconsts + g0, &nb))
+      return khg_set_error(KHG_E_RUNTIME, "At component of pdf " + std::to_string(p) + ", not a number in gconst computation");
+  }
+  if (num_bad_out) *num_bad_out = nb;
+  return KHG_OK;
+}
+
+extern "C" int khg_mle_am_diag_gmm_update(const khg_mle_options* o, int32_t P, int32_t D, const int32_t* gauss_off,
+                                          const double* occ, const double* mean_acc, const double* var_acc,
+                                          uint16_t acc_flags, uint16_t flags, float* weights, float* gconsts,
+                                          float* means_invvars, float* inv_vars, int32_t* new_gauss_off,
+                                          float* objf_change, float* count, int32_t* floored_elems,
+                                          int32_t* floored_gauss, int32_t* removed) {
+  if (!o || P <= 0 || D <= 0 || !gauss_off || !occ || !weights || !gconsts || !means_invvars || !inv_vars || !new_gauss_off)
+    return khg_set_error(KHG_E_ARG, "khg_mle_am_diag_gmm_update: bad arguments");
+  if (flags & ~acc_flags) return khg_set_error(KHG_E_RUNTIME, "Flags in argument do not match the active accumulators");  // mle-diag-gmm.cc:252
+  if ((acc_flags & kMeans) && !mean_acc) return khg_set_error(KHG_E_ARG, "mean accumulator missing");
+  if ((acc_flags & kVars) && !var_acc) return khg_set_error(KHG_E_ARG, "variance accumulator missing");
+  // csrc/mle-am-diag-gmm.cc:153-202: float running totals
+  float tot_obj = 0.0f, tot_count = 0.0f;
+  int tfe = 0, tfg = 0, trm = 0;
+  int out = 0;
+  std::vector<float> w, gc, miv, iv;
+  for (int p = 0; p < P; ++p) {
+    const int g0 = gauss_off[p], G = gauss_off[p + 1] - g0;
+    w.assign(weights + g0, weights + g0 + G);
+    gc.assign(G, 0.0f);
+    miv.assign(means_invvars + (size_t)g0 * D, means_invvars + (size_t)(g0 + G) * D);
+    iv.assign(inv_vars + (size_t)g0 * D, inv_vars + (size_t)(g0 + G) * D);
+    UpdateResult r;
+    if (!MleUpdateOne(*o, D, occ + g0, mean_acc ? mean_acc + (size_t)g0 * D : nullptr,
+                      var_acc ? var_acc + (size_t)g0 * D : nullptr, acc_flags, flags, w, gc, miv, iv, &r))
+      return khg_set_error(KHG_E_RUNTIME, "pdf " + std::to_string(p) + ": not a number in gconst computation");
+    tot_obj += r.obj_change; tot_count += r.count; tfe += r.floored_elems; tfg += r.floored_gauss; trm += r.removed;
+    const int Gn = (int)w.size();
+    new_gauss_off[p] = out;
+    // compaction is in place and never overtakes the read cursor (out <= g0)
+    std::copy(w.begin(), w.end(), weights + out);
+    std::copy(gc.begin(), gc.end(), gconsts + out);
+    std::copy(miv.begin(), miv.end(), means_invvars + (size_t)out * D);
+    std::copy(iv.begin(), iv.end(), inv_vars + (size_t)out * D);
+    out += Gn;
+  }
+  new_gauss_off[P] = out;
+  if (objf_change) *objf_change = tot_obj;
+  if (count) *count = tot_count;
+  if (floored_elems) *floored_elems = tfe;
+  if (floored_gauss) *floored_gauss = tfg;
+  if (removed) *removed = trm;
+  return KHG_OK;
+}
+
+// csrc/transition-model.cc:657-750 (share_for_pdfs == false) + :339-359
+extern "C" int khg_transition_mle_update(int32_t num_tstates, const int32_t* state2id, const int32_t* self_loop_of,
+                                         const double* stats, float floor_, float mincount, float* log_probs,
+                                         float* nsl, float* objf_impr, float* count) {
+  if (num_tstates <= 0 || !state2id || !self_loop_of || !stats || !log_probs || !nsl)
+    return khg_set_error(KHG_E_ARG, "khg_transition_mle_update: bad arguments");
+  float count_sum = 0.0f, objf_impr_sum = 0.0f;
+  std::vector<float> new_probs, old_probs;
+  for (int ts = 1; ts <= num_tstates; ++ts) {
+    const int first = state2id[ts], n = state2id[ts + 1] - first;
+    if (n < 1) return khg_set_error(KHG_E_RUNTIME, "transition-state with no transitions");
+    if (n == 1) continue;
+    double tot = 0;
+    for (int k = 0; k < n; ++k) tot += stats[first + k];
+    count_sum += tot;
+    if (tot < mincount) continue;
+    new_probs.resize(n); old_probs.resize(n);
+    for (int k = 0; k < n; ++k) { old_probs[k] = std::exp(log_probs[first + k]); new_probs[k] = stats[first + k] / tot; }
+    for (int it = 0; it < 3; ++it) {  // floor + renormalise three times (:693-699)
+      float s = 0.0f;
+      for (float x : new_probs) s += x;
+      for (float& x : new_probs) { x /= s; }
+      for (float& x : new_probs) x = std::max(x, floor_);
+    }
+    for (int k = 0; k < n; ++k) {
+      const double ch = stats[first + k] * (std::log(new_probs[k]) - std::log(old_probs[k]));
+      objf_impr_sum += ch;
+    }
+    for (int k = 0; k < n; ++k) {
+      const float lp = std::log(new_probs[k]);
+      if (lp - lp != 0.0f) return khg_set_error(KHG_E_RUNTIME, "Log probs is inf or NaN: error in update or bad stats?");
+      log_probs[first + k] = lp;
+    }
+  }
+  if (objf_impr) *objf_impr = objf_impr_sum;
+  if (count) *count = count_sum;
+  for (int ts = 1; ts <= num_tstates; ++ts) {
+    const int tid = self_loop_of[ts];
+    if (tid == 0) { nsl[ts] = 0.0f; continue; }
+    const float slp = std::exp(log_probs[tid]);
+    float nslp = 1.0 - slp;
+    if (nslp <= 0.0) nslp = 1.0e-10;
+    nsl[ts] = std::log(nslp);
+  }
+  return KHG_OK;
+}
+
+// csrc/hmm-utils.cc:442-463, negated (what AddTransitionProbs multiplies into the arc weight)
+extern "C" int khg_scaled_trans_cost(int32_t num_tids, const float* log_probs, const float* nsl, const int32_t* id2state,
+                                     const uint8_t* is_self_loop, float transition_scale, float self_loop_scale, float* out) {
+  if (num_tids <= 0 || !log_probs || !nsl || !id2state || !is_self_loop || !out)
+    return khg_set_error(KHG_E_ARG, "khg_scaled_trans_cost: bad arguments");
+  out[0] = 0.0f;
+  for (int tid = 1; tid <= num_tids; ++tid) {
+    float s;
+    if (transition_scale == self_loop_scale) s = log_probs[tid] * transition_scale;
+    else if (is_self_loop[tid]) s = self_loop_scale * log_probs[tid];
+    else {
+      const int ts = id2state[tid];
+      const float ignoring = log_probs[tid] - nsl[ts];  // GetTransitionLogProbIgnoringSelfLoops
+      s = self_loop_scale * nsl[ts] + transition_scale * ignoring;
+    }
+    out[tid] = -s;
+  }
+  return KHG_OK;
+}

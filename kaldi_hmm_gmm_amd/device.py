@@ -1,0 +1,298 @@
+"""Device-resident objects of the batched EM path: thin owners of the C-ABI handles.
+
+Batched counterparts of what scripts/gmm_align_compiled.py and scripts/gmm_acc_stats_ali.py
+(reference) do one utterance / one frame at a time.
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+INT32_MAX = 2**31 - 1
+
+ALIGN_DONE = 0
+ALIGN_ERROR = 1
+ALIGN_RETRIED = 2
+ALIGN_EXACT_DP = 4
+ALIGN_FALLBACK = 8
+
+
+class Context:
+    """khg_ctx: one per process / GPU.  `stream` may be a raw hipStream_t handle (int), e.g.
+    torch.cuda.current_stream().cuda_stream."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.h = C.c_void_p()
+        check(lib.khg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.device = device
+
+    def sync(self):
+        check(lib.khg_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib.khg_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceModel:
+    """AmDiagGmm uploaded as the K1 tile image + K3 row-major copy."""
+
+    def __init__(self, ctx: Context, gauss_off, gconsts, means_invvars, inv_vars):
+        self.ctx = ctx
+        go = _lib.as_np(gauss_off, np.int32)
+        gc = _lib.as_np(gconsts, np.float32)
+        miv = _lib.as_np(means_invvars, np.float32)
+        iv = _lib.as_np(inv_vars, np.float32)
+        self.num_pdfs = go.shape[0] - 1
+        self.dim = miv.shape[1]
+        self.gauss_off = go
+        assert miv.shape == iv.shape and miv.shape[0] == go[-1] == gc.shape[0]
+        self.h = C.c_void_p()
+        check(lib.khg_model_create(ctx.h, self.num_pdfs, self.dim, ptr(go, C.c_int32), ptr(gc, C.c_float),
+                                   ptr(miv, C.c_float), ptr(iv, C.c_float), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib.khg_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceTransitions:
+    """TransitionIdToPdf table + the per-tid cost AddTransitionProbs adds to graph arcs."""
+
+    def __init__(self, ctx: Context, id2pdf):
+        self.ctx = ctx
+        self.id2pdf = _lib.as_np(id2pdf, np.int32)
+        self.num_tids = self.id2pdf.shape[0] - 1
+        self.h = C.c_void_p()
+        check(lib.khg_tm_create(ctx.h, self.num_tids, ptr(self.id2pdf, C.c_int32), C.byref(self.h)))
+
+    def set_trans_cost(self, cost):
+        if cost is None:
+            check(lib.khg_tm_set_trans_cost(self.h, None))
+        else:
+            c = _lib.as_np(cost, np.float32)
+            assert c.shape[0] == self.num_tids + 1
+            check(lib.khg_tm_set_trans_cost(self.h, ptr(c, C.c_float)))
+
+    def close(self):
+        if self.h:
+            lib.khg_tm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class UtteranceSet:
+    """Features (+ decoding graphs) of a shard of utterances, resident in HBM.
+
+    graphs: dict with state_off[U+1], start[U], arc_off[sumS+1], ilabel, olabel, weight,
+    nextstate, final[sumS]  (CSR by source state, utterance-local nextstate), or None.
+    feats: float32 [N, D] numpy array, or (device_ptr:int, keepalive) for data already in HBM.
+    """
+
+    def __init__(self, ctx: Context, tm: Optional[DeviceTransitions], frame_off, feats, dim=None, graphs=None):
+        self.ctx = ctx
+        self.frame_off = _lib.as_np(frame_off, np.int64)
+        self.n_utt = self.frame_off.shape[0] - 1
+        self._keep = []
+        feats_h = None
+        feats_d = None
+        if isinstance(feats, tuple):
+            feats_d, keep = feats
+            self._keep.append(keep)
+            assert dim is not None
+        else:
+            feats_h = _lib.as_np(feats, np.float32)
+            dim = feats_h.shape[1]
+            assert feats_h.shape[0] == self.frame_off[-1]
+        self.dim = int(dim)
+        g = graphs
+        if g is not None:
+            self._g = {k: _lib.as_np(g[k], dt) for k, dt in (
+                ("state_off", np.int64), ("start", np.int32), ("arc_off", np.int64), ("ilabel", np.int32),
+                ("olabel", np.int32), ("weight", np.float32), ("nextstate", np.int32), ("final", np.float32))}
+            gg = self._g
+            args = (ptr(gg["state_off"], C.c_int64), ptr(gg["start"], C.c_int32), ptr(gg["arc_off"], C.c_int64),
+                    ptr(gg["ilabel"], C.c_int32), ptr(gg["olabel"], C.c_int32), ptr(gg["weight"], C.c_float),
+                    ptr(gg["nextstate"], C.c_int32), ptr(gg["final"], C.c_float))
+        else:
+            args = (None,) * 8
+        self.h = C.c_void_p()
+        check(lib.khg_utts_create(ctx.h, tm.h if tm is not None else None, self.n_utt, self.dim,
+                                  ptr(self.frame_off, C.c_int64), ptr(feats_h, C.c_float) if feats_h is not None else None,
+                                  C.c_void_p(feats_d) if feats_d else None, *args, C.byref(self.h)))
+        self._g = None  # the library keeps its own device copy
+
+    # -- pdf lists / log-likes -------------------------------------------------------------
+    def set_pdf_list(self, pdfs):
+        p = _lib.as_np(pdfs, np.int32)
+        check(lib.khg_utts_set_pdf_list(self.h, p.shape[0], ptr(p, C.c_int32)))
+
+    def pdf_lists(self):
+        off = np.zeros(self.n_utt + 1, np.int64)
+        check(lib.khg_utts_num_pdfs(self.h, ptr(off, C.c_int64)))
+        pdfs = np.zeros(max(int(off[-1]), 1), np.int32)
+        check(lib.khg_utts_pdfs(self.h, ptr(pdfs, C.c_int32)))
+        return off, pdfs[: int(off[-1])]
+
+    def loglikes(self, model: DeviceModel):
+        check(lib.khg_loglikes(self.ctx.h, model.h, self.h))
+
+    def loglikes_layout(self):
+        off = np.zeros(self.n_utt + 1, np.int64)
+        tot = C.c_int64()
+        check(lib.khg_loglikes_layout(self.h, ptr(off, C.c_int64), C.byref(tot)))
+        return off, tot.value
+
+    def download_loglikes(self):
+        """-> list of [npdf_u, T_u] float32 arrays (padding columns stripped)."""
+        off, tot = self.loglikes_layout()
+        buf = np.zeros(max(tot, 1), np.float32)
+        check(lib.khg_loglikes_download(self.ctx.h, self.h, ptr(buf, C.c_float)))
+        poff, _ = self.pdf_lists()
+        out = []
+        for u in range(self.n_utt):
+            T = int(self.frame_off[u + 1] - self.frame_off[u])
+            tpad = (T + 31) // 32 * 32
+            n = int(poff[u + 1] - poff[u])
+            out.append(buf[off[u]: off[u] + n * tpad].reshape(n, tpad)[:, :T].copy())
+        return out
+
+    def upload_loglikes(self, mats):
+        off, tot = self.loglikes_layout()
+        buf = np.zeros(max(tot, 1), np.float32)
+        for u, m in enumerate(mats):
+            T = int(self.frame_off[u + 1] - self.frame_off[u])
+            tpad = (T + 31) // 32 * 32
+            n = m.shape[0]
+            v = buf[off[u]: off[u] + n * tpad].reshape(n, tpad)
+            v[:, :T] = m
+        check(lib.khg_loglikes_upload(self.ctx.h, self.h, ptr(buf, C.c_float)))
+
+    # -- alignment ---------------------------------------------------------------------------
+    def align(self, tm: DeviceTransitions, beam=200.0, retry_beam=0.0, acoustic_scale=1.0, careful=False,
+              max_active=INT32_MAX, min_active=20, beam_delta=0.5, hash_ratio=2.0, download=True):
+        cfg = _lib.AlignConfigC(beam, retry_beam, int(careful), acoustic_scale, max_active, min_active, beam_delta,
+                                hash_ratio)
+        if not download:
+            check(lib.khg_align(self.ctx.h, tm.h, self.h, C.byref(cfg), None, None, None, 0, None, None))
+            return None
+        N = int(self.frame_off[-1])
+        ali = np.zeros(max(N, 1), np.int32)
+        like = np.zeros(self.n_utt, np.float32)
+        status = np.zeros(self.n_utt, np.int32)
+        wcap = N + 16 * self.n_utt + 1024
+        words = np.zeros(wcap, np.int32)
+        woff = np.zeros(self.n_utt + 1, np.int64)
+        check(lib.khg_align(self.ctx.h, tm.h, self.h, C.byref(cfg), ptr(ali, C.c_int32), ptr(words, C.c_int32),
+                            ptr(woff, C.c_int64), wcap, ptr(like, C.c_float), ptr(status, C.c_int32)))
+        return {"ali": ali[:N], "like": like, "status": status, "words": words[: int(woff[-1])], "words_off": woff}
+
+    def upload_ali(self, ali):
+        a = _lib.as_np(ali, np.int32)
+        assert a.shape[0] == self.frame_off[-1]
+        check(lib.khg_ali_upload(self.ctx.h, self.h, ptr(a, C.c_int32)))
+
+    def acc_stats(self, model: DeviceModel, tm: DeviceTransitions, accs: "DeviceAccs", weight: float = 1.0):
+        check(lib.khg_acc_stats(self.ctx.h, model.h, tm.h, self.h, float(weight), accs.h))
+
+    def close(self):
+        if self.h:
+            lib.khg_utts_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceAccs:
+    """AccumAmDiagGmm + transition stats as one fp64 device buffer (see include/khg_hip.h)."""
+
+    def __init__(self, ctx: Context, model: DeviceModel, tm: DeviceTransitions):
+        self.ctx = ctx
+        self.sumG = int(model.gauss_off[-1])
+        self.dim = model.dim
+        self.num_tids = tm.num_tids
+        self.h = C.c_void_p()
+        check(lib.khg_accs_create(ctx.h, model.h, tm.h, C.byref(self.h)))
+        n = C.c_int64()
+        check(lib.khg_accs_size(self.h, C.byref(n)))
+        self.size = n.value
+
+    def zero(self):
+        check(lib.khg_accs_zero(self.ctx.h, self.h))
+
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        check(lib.khg_accs_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def as_torch(self):
+        """Zero-copy torch view of the device buffer (for torch.distributed.all_reduce over RCCL)."""
+        import torch
+
+        class _W:
+            pass
+
+        w = _W()
+        w.__cuda_array_interface__ = {"shape": (self.size,), "typestr": "<f8", "data": (self.device_ptr(), False),
+                                      "version": 2, "strides": None}
+        t = torch.as_tensor(w, device=f"cuda:{self.ctx.device}")
+        t._khg_keepalive = self
+        return t
+
+    def split(self, buf):
+        G, D, nt = self.sumG, self.dim, self.num_tids
+        o = 0
+        occ = buf[o: o + G]; o += G
+        mean = buf[o: o + G * D].reshape(G, D); o += G * D
+        var = buf[o: o + G * D].reshape(G, D); o += G * D
+        trans = buf[o: o + nt + 1]; o += nt + 1
+        scal = buf[o: o + 8]
+        return {"occ": occ, "mean_acc": mean, "var_acc": var, "trans_acc": trans, "total_frames": float(scal[0]),
+                "total_log_like": float(scal[1])}
+
+    def download(self):
+        buf = np.zeros(self.size, np.float64)
+        check(lib.khg_accs_download(self.ctx.h, self.h, ptr(buf, C.c_double)))
+        return self.split(buf)
+
+    def upload(self, buf):
+        b = _lib.as_np(buf, np.float64)
+        assert b.shape[0] == self.size
+        check(lib.khg_accs_upload(self.ctx.h, self.h, ptr(b, C.c_double)))
+
+    def close(self):
+        if self.h:
+            lib.khg_accs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,205 @@
+"""Synthetic HMM-GMM workloads: model, transition tables, per-utterance
+training graphs and features sampled from the model.  Used by tests and bench.py.
+
+Graph shape follows what the reference's TrainingGraphCompiler emits for a linear transcript
+with reorder=true (csrc/hmm-utils.cc:293-369): a chain g_0 .. g_S where
+the arc g_i -> g_{i+1} carries the FORWARD transition-id of HMM-state i and g_{i+1} carries the
+self-loop of HMM-state i, so a state held d frames emits [forward, self-loop x (d-1)].
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+CONFIGS = {
+    # name: (num_pdfs, gauss_per_pdf, dim)   -- BASELINE.json configs[1..4]
+    "mono100x8": (100, 8, 39),
+    "tri2000x32": (2000, 32, 40),
+    "tri5000x64": (5000, 64, 40),
+    "stress10000x128": (10000, 128, 80),
+}
+
+
+@dataclass
+class SynthModel:
+    gauss_off: np.ndarray       # int32 [P+1]
+    weights: np.ndarray         # float32 [sumG]
+    means: np.ndarray           # float32 [sumG, D]
+    vars: np.ndarray            # float32 [sumG, D]
+    inv_vars: np.ndarray        # float32 [sumG, D]
+    means_invvars: np.ndarray   # float32 [sumG, D]
+    # transition tables of a 3-state left-to-right monophone-style model
+    # (csrc/transition-model.cc:254-303,318-359): tstate = pdf+1, tids (2*pdf+1: self-loop, 2*pdf+2: forward)
+    id2pdf: np.ndarray          # int32 [num_tids+1]
+    id2state: np.ndarray        # int32 [num_tids+1]
+    is_self_loop: np.ndarray    # uint8 [num_tids+1]
+    state2id: np.ndarray        # int32 [num_tstates+2]
+    self_loop_of: np.ndarray    # int32 [num_tstates+1]
+    log_probs: np.ndarray       # float32 [num_tids+1]
+    non_self_loop_log_probs: np.ndarray  # float32 [num_tstates+1]
+
+    @property
+    def num_pdfs(self):
+        return self.gauss_off.shape[0] - 1
+
+    @property
+    def dim(self):
+        return self.means.shape[1]
+
+    @property
+    def num_tids(self):
+        return self.id2pdf.shape[0] - 1
+
+
+def make_model(num_pdfs, gauss, dim, seed=20230414, ragged=False, self_loop_prob=0.75):
+    rng = np.random.default_rng(seed)
+    if ragged:
+        g = rng.integers(max(1, gauss // 2), gauss + 1, size=num_pdfs)
+    else:
+        g = np.full(num_pdfs, gauss)
+    gauss_off = np.concatenate([[0], np.cumsum(g)]).astype(np.int32)
+    sumG = int(gauss_off[-1])
+    means = (3.0 * rng.standard_normal((sumG, dim))).astype(np.float32)
+    var = rng.uniform(0.5, 2.0, size=(sumG, dim)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=sumG).astype(np.float32)
+    for p in range(num_pdfs):
+        sl = slice(gauss_off[p], gauss_off[p + 1])
+        w[sl] /= w[sl].sum()
+    inv_vars = (1.0 / var).astype(np.float32)
+    means_invvars = (means * inv_vars).astype(np.float32)
+    nt = 2 * num_pdfs
+    tid = np.arange(nt + 1)
+    id2pdf = np.where(tid > 0, (tid - 1) // 2, 0).astype(np.int32)
+    id2state = (id2pdf + 1).astype(np.int32)
+    id2state[0] = 0
+    is_self_loop = ((tid % 2) == 1).astype(np.uint8)
+    is_self_loop[0] = 0
+    state2id = (2 * np.arange(num_pdfs + 2) - 1).astype(np.int32)  # state2id[ts] = 2(ts-1)+1
+    state2id[0] = 0
+    self_loop_of = state2id[: num_pdfs + 1].copy()
+    self_loop_of[0] = 0
+    log_probs = np.zeros(nt + 1, np.float32)
+    log_probs[1::2] = np.log(np.float32(self_loop_prob))
+    log_probs[2::2] = np.log(np.float32(1.0 - self_loop_prob))
+    nsl = np.zeros(num_pdfs + 1, np.float32)
+    nsl[1:] = np.log(np.float32(1.0) - np.exp(np.log(np.float32(self_loop_prob))))
+    return SynthModel(gauss_off, w, means, var, inv_vars, means_invvars, id2pdf, id2state, is_self_loop, state2id,
+                      self_loop_of, log_probs, nsl)
+
+
+@dataclass
+class SynthUtts:
+    frame_off: np.ndarray   # int64 [U+1]
+    feats: object           # float32 [N, D] numpy, or None when generated on the device
+    ref_ali: np.ndarray     # int32 [N] generating transition-id sequence
+    frame_pdf: np.ndarray   # int32 [N]
+    graphs: dict            # CSR arrays (see device.UtteranceSet)
+    num_phones: np.ndarray  # [U]
+
+
+def make_utts(model: SynthModel, n_utt, seed=1, min_phones=10, max_phones=40, leave_prob=0.25, feats=True,
+              shuffle_phones=True):
+    """Utterances of L ~ U{min..max} phones x 3 HMM states; state durations 1 + Geom(leave_prob)."""
+    rng = np.random.default_rng(seed)
+    P = model.num_pdfs
+    nphones = P // 3
+    assert nphones >= 1, "need at least 3 pdfs"
+    L = rng.integers(min_phones, max_phones + 1, size=n_utt)
+    nst = 3 * L                                   # emitting HMM states per utterance
+    tot_states = int(nst.sum())
+    phones = rng.integers(0, nphones, size=int(L.sum()))
+    state_pdf = (3 * np.repeat(phones, 3) + np.tile(np.arange(3), phones.shape[0])).astype(np.int32)
+    dur = rng.geometric(leave_prob, size=tot_states).astype(np.int64)  # >= 1
+    st_off = np.concatenate([[0], np.cumsum(nst)])
+    T = np.add.reduceat(dur, st_off[:-1])
+    frame_off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+    N = int(frame_off[-1])
+    frame_pdf = np.repeat(state_pdf, dur)
+    # generating alignment: forward tid on the first frame of each state, self-loop afterwards
+    first = np.zeros(N, bool)
+    first[np.concatenate([[0], np.cumsum(dur)[:-1]])] = True
+    ref_ali = np.where(first, 2 * frame_pdf + 2, 2 * frame_pdf + 1).astype(np.int32)
+
+    # graphs: per utterance S = nst+1 states, arcs: g_0:[fwd0]; g_i:[fwd_i, loop_{i-1}]; g_S:[loop_{S-1}]
+    S = nst + 1
+    state_off = np.concatenate([[0], np.cumsum(S)]).astype(np.int64)
+    NS = int(state_off[-1])
+    narcs_state = np.full(NS, 2, np.int64)
+    narcs_state[state_off[:-1]] = 1
+    narcs_state[state_off[1:] - 1] = 1
+    arc_off = np.concatenate([[0], np.cumsum(narcs_state)]).astype(np.int64)
+    NA = int(arc_off[-1])
+    ilabel = np.zeros(NA, np.int32)
+    nextstate = np.zeros(NA, np.int32)
+    local = np.arange(NS) - np.repeat(state_off[:-1], S)           # local state index
+    # emitting-state index (into state_pdf) of local state i of utterance u is st_off[u] + i
+    base = np.repeat(st_off[:-1], S)
+    is_last = local == np.repeat(nst, S)
+    is_first = local == 0
+    # forward arc (first arc of every non-last state)
+    fwd_states = np.nonzero(~is_last)[0]
+    a = arc_off[fwd_states]
+    ilabel[a] = 2 * state_pdf[base[fwd_states] + local[fwd_states]] + 2
+    nextstate[a] = local[fwd_states] + 1
+    # self-loop arc (last arc of every non-first state)
+    loop_states = np.nonzero(~is_first)[0]
+    a = arc_off[loop_states + 1] - 1
+    ilabel[a] = 2 * state_pdf[base[loop_states] + local[loop_states] - 1] + 1
+    nextstate[a] = local[loop_states]
+    final = np.full(NS, np.inf, np.float32)
+    final[state_off[1:] - 1] = 0.0
+    graphs = {
+        "state_off": state_off,
+        "start": np.zeros(n_utt, np.int32),
+        "arc_off": arc_off,
+        "ilabel": ilabel,
+        "olabel": np.zeros(NA, np.int32),
+        "weight": np.zeros(NA, np.float32),
+        "nextstate": nextstate,
+        "final": final,
+    }
+    x = sample_feats(model, frame_pdf, rng) if feats else None
+    return SynthUtts(frame_off, x, ref_ali, frame_pdf.astype(np.int32), graphs, L)
+
+
+def sample_feats(model: SynthModel, frame_pdf, rng, chunk=1 << 18):
+    """x ~ N(mean, var) of a component drawn by weight from the frame's pdf (numpy, host)."""
+    N = frame_pdf.shape[0]
+    D = model.dim
+    out = np.empty((N, D), np.float32)
+    go = model.gauss_off
+    cw = np.cumsum(model.weights.astype(np.float64))
+    base = np.concatenate([[0.0], cw])[go[:-1]]   # cumulative weight before each pdf's first Gaussian
+    for s in range(0, N, chunk):
+        p = frame_pdf[s: s + chunk]
+        r = rng.random(p.shape[0]) * (cw[go[p + 1] - 1] - base[p]) + base[p]
+        comp = np.searchsorted(cw, r, side="right")
+        comp = np.minimum(np.maximum(comp, go[p]), go[p + 1] - 1)
+        z = rng.standard_normal((p.shape[0], D)).astype(np.float32)
+        out[s: s + chunk] = model.means[comp] + np.sqrt(model.vars[comp]) * z
+    return out
+
+
+def sample_feats_torch(model: SynthModel, frame_pdf, seed, device, chunk=1 << 22):
+    """Same law as sample_feats, generated directly in HBM with torch (bench-sized sets)."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    N = frame_pdf.shape[0]
+    D = model.dim
+    out = torch.empty((N, D), dtype=torch.float32, device=device)
+    go = torch.as_tensor(model.gauss_off.astype(np.int64), device=device)
+    cw = torch.cumsum(torch.as_tensor(model.weights, device=device).double(), 0)
+    base = torch.cat([torch.zeros(1, device=device, dtype=torch.float64), cw])[go[:-1]]
+    means = torch.as_tensor(model.means, device=device)
+    std = torch.sqrt(torch.as_tensor(model.vars, device=device))
+    fp = torch.as_tensor(frame_pdf.astype(np.int64), device=device)
+    for s in range(0, N, chunk):
+        p = fp[s: s + chunk]
+        r = torch.rand(p.shape[0], device=device, dtype=torch.float64, generator=gen)
+        r = r * (cw[go[p + 1] - 1] - base[p]) + base[p]
+        comp = torch.searchsorted(cw, r, right=True)
+        comp = torch.minimum(torch.maximum(comp, go[p]), go[p + 1] - 1)
+        z = torch.randn((p.shape[0], D), device=device, dtype=torch.float32, generator=gen)
+        out[s: s + chunk] = means[comp] + std[comp] * z
+    return out

@@ -1,0 +1,306 @@
+"""ctypes binding of oracle/libkhg_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+See khg_oracle.h for the pinning status ("PARITY UNPINNED" for the decoder / M-step).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libkhg_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("khg_oracle.c", "khg_oracle.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "libkhg_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class Model(C.Structure):
+    _fields_ = [("num_pdfs", C.c_int32), ("dim", C.c_int32), ("gauss_off", C.POINTER(C.c_int32)),
+                ("gconsts", C.POINTER(C.c_float)), ("means_invvars", C.POINTER(C.c_float)),
+                ("inv_vars", C.POINTER(C.c_float))]
+
+
+class Graph(C.Structure):
+    _fields_ = [("num_states", C.c_int32), ("start", C.c_int32), ("arc_off", C.POINTER(C.c_int32)),
+                ("ilabel", C.POINTER(C.c_int32)), ("olabel", C.POINTER(C.c_int32)), ("weight", C.POINTER(C.c_float)),
+                ("nextstate", C.POINTER(C.c_int32)), ("final", C.POINTER(C.c_float))]
+
+
+class AlignConfig(C.Structure):
+    _fields_ = [("beam", C.c_float), ("retry_beam", C.c_float), ("careful", C.c_int32), ("max_active", C.c_int32),
+                ("min_active", C.c_int32), ("beam_delta", C.c_float), ("hash_ratio", C.c_float)]
+
+
+class AlignStats(C.Structure):
+    _fields_ = [("loglike_evals", C.c_int64), ("tokens_expanded", C.c_int64)]
+
+
+class Accs(C.Structure):
+    _fields_ = [("occ", C.POINTER(C.c_double)), ("mean_acc", C.POINTER(C.c_double)), ("var_acc", C.POINTER(C.c_double)),
+                ("trans_acc", C.POINTER(C.c_double)), ("total_frames", C.c_double), ("total_log_like", C.c_double)]
+
+
+class MleOpts(C.Structure):
+    _fields_ = [("min_gaussian_weight", C.c_float), ("min_gaussian_occupancy", C.c_float), ("min_variance", C.c_double),
+                ("remove_low_count_gaussians", C.c_int32)]
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_logsumexp.restype = C.c_float
+        _lib.orc_softmax.restype = C.c_float
+        _lib.orc_ml_objective.restype = C.c_float
+        _lib.orc_augment_gmm_flags.restype = C.c_uint16
+        _lib.orc_augment_gmm_flags.argtypes = [C.c_uint16]
+    return _lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise OracleError(f"{what}: oracle error {rc}")
+
+
+f32 = np.float32
+
+
+class OModel:
+    """Ragged AmDiagGmm for the oracle (keeps the numpy arrays alive)."""
+
+    def __init__(self, gauss_off, gconsts, means_invvars, inv_vars):
+        self.gauss_off = np.ascontiguousarray(gauss_off, np.int32)
+        self.gconsts = np.ascontiguousarray(gconsts, f32)
+        self.miv = np.ascontiguousarray(means_invvars, f32)
+        self.iv = np.ascontiguousarray(inv_vars, f32)
+        self.c = Model(self.gauss_off.shape[0] - 1, self.miv.shape[1], _p(self.gauss_off, C.c_int32),
+                       _p(self.gconsts, C.c_float), _p(self.miv, C.c_float), _p(self.iv, C.c_float))
+
+
+class OGraph:
+    def __init__(self, start, arc_off, ilabel, olabel, weight, nextstate, final):
+        self.arc_off = np.ascontiguousarray(arc_off, np.int32)
+        self.ilabel = np.ascontiguousarray(ilabel, np.int32)
+        self.olabel = np.ascontiguousarray(olabel, np.int32)
+        self.weight = np.ascontiguousarray(weight, f32)
+        self.nextstate = np.ascontiguousarray(nextstate, np.int32)
+        self.final = np.ascontiguousarray(final, f32)
+        self.c = Graph(self.final.shape[0], int(start), _p(self.arc_off, C.c_int32), _p(self.ilabel, C.c_int32),
+                       _p(self.olabel, C.c_int32), _p(self.weight, C.c_float), _p(self.nextstate, C.c_int32),
+                       _p(self.final, C.c_float))
+
+    @staticmethod
+    def from_set(graphs, u):
+        """Slice utterance u out of the concatenated CSR used by the product."""
+        s0, s1 = int(graphs["state_off"][u]), int(graphs["state_off"][u + 1])
+        ao = graphs["arc_off"][s0: s1 + 1]
+        a0, a1 = int(ao[0]), int(ao[-1])
+        return OGraph(graphs["start"][u], ao - a0, graphs["ilabel"][a0:a1], graphs["olabel"][a0:a1],
+                      graphs["weight"][a0:a1], graphs["nextstate"][a0:a1], graphs["final"][s0:s1])
+
+
+def compute_gconsts(weights, inv_vars, means_invvars):
+    w = np.ascontiguousarray(weights, f32); iv = np.ascontiguousarray(inv_vars, f32)
+    miv = np.ascontiguousarray(means_invvars, f32)
+    out = np.zeros(w.shape[0], f32)
+    nb = C.c_int32()
+    _chk(lib().orc_compute_gconsts(w.shape[0], iv.shape[1], _p(w, C.c_float), _p(iv, C.c_float), _p(miv, C.c_float),
+                                   _p(out, C.c_float), C.byref(nb)), "compute_gconsts")
+    return out, nb.value
+
+
+def model_gconsts(gauss_off, weights, inv_vars, means_invvars):
+    out = np.zeros(weights.shape[0], f32)
+    for p in range(len(gauss_off) - 1):
+        a, b = gauss_off[p], gauss_off[p + 1]
+        out[a:b], _ = compute_gconsts(weights[a:b], inv_vars[a:b], means_invvars[a:b])
+    return out
+
+
+def loglikes(gconsts, means_invvars, inv_vars, x, fma_order=False):
+    gc = np.ascontiguousarray(gconsts, f32); miv = np.ascontiguousarray(means_invvars, f32)
+    iv = np.ascontiguousarray(inv_vars, f32); x = np.ascontiguousarray(x, f32)
+    out = np.zeros(gc.shape[0], f32)
+    fn = lib().orc_loglikes_fma_order if fma_order else lib().orc_loglikes
+    fn(gc.shape[0], miv.shape[1], _p(gc, C.c_float), _p(miv, C.c_float), _p(iv, C.c_float), _p(x, C.c_float),
+       _p(out, C.c_float))
+    return out
+
+
+def logsumexp(v):
+    v = np.ascontiguousarray(v, f32)
+    return float(lib().orc_logsumexp(v.shape[0], _p(v, C.c_float)))
+
+
+def softmax(v):
+    v = np.ascontiguousarray(v, f32)
+    out = np.zeros_like(v)
+    lse = lib().orc_softmax(v.shape[0], _p(v, C.c_float), _p(out, C.c_float))
+    return out, float(lse)
+
+
+def component_posteriors(m: OModel, pdf, x):
+    x = np.ascontiguousarray(x, f32)
+    G = int(m.gauss_off[pdf + 1] - m.gauss_off[pdf])
+    post = np.zeros(G, f32)
+    ll = C.c_float()
+    _chk(lib().orc_component_posteriors(C.byref(m.c), int(pdf), _p(x, C.c_float), _p(post, C.c_float), C.byref(ll)),
+         "component_posteriors")
+    return post, ll.value
+
+
+def loglikes_matrix(m: OModel, feats, pdfs):
+    feats = np.ascontiguousarray(feats, f32); pdfs = np.ascontiguousarray(pdfs, np.int32)
+    out = np.zeros((pdfs.shape[0], feats.shape[0]), f32)
+    _chk(lib().orc_loglikes_matrix(C.byref(m.c), feats.shape[0], _p(feats, C.c_float), pdfs.shape[0],
+                                   _p(pdfs, C.c_int32), _p(out, C.c_float)), "loglikes_matrix")
+    return out
+
+
+def add_transition_probs(ilabel, weight, log_probs, nsl, id2state, is_self_loop, transition_scale, self_loop_scale,
+                         disambig=()):
+    il = np.ascontiguousarray(ilabel, np.int32); w = np.array(weight, f32, copy=True)
+    lp = np.ascontiguousarray(log_probs, f32); ns = np.ascontiguousarray(nsl, f32)
+    i2s = np.ascontiguousarray(id2state, np.int32); sl = np.ascontiguousarray(is_self_loop, np.uint8)
+    dis = np.ascontiguousarray(sorted(disambig), np.int32)
+    _chk(lib().orc_add_transition_probs(il.shape[0], _p(il, C.c_int32), _p(w, C.c_float), lp.shape[0] - 1,
+                                        _p(lp, C.c_float), _p(ns, C.c_float), _p(i2s, C.c_int32), _p(sl, C.c_uint8),
+                                        C.c_float(transition_scale), C.c_float(self_loop_scale), dis.shape[0],
+                                        _p(dis, C.c_int32)), "add_transition_probs")
+    return w
+
+
+def careful_graph(g: OGraph):
+    S = g.final.shape[0]; A = g.ilabel.shape[0]
+    ao = np.zeros(2 * S + 2, np.int32); il = np.zeros(2 * A + S + 1, np.int32); ol = np.zeros_like(il)
+    w = np.zeros(2 * A + S + 1, f32); ns = np.zeros_like(il); fin = np.zeros(2 * S + 1, f32)
+    nS = C.c_int32(); st = C.c_int32(); nA = C.c_int32()
+    _chk(lib().orc_careful_graph(C.byref(g.c), C.byref(nS), C.byref(st), _p(ao, C.c_int32), _p(il, C.c_int32),
+                                 _p(ol, C.c_int32), _p(w, C.c_float), _p(ns, C.c_int32), _p(fin, C.c_float),
+                                 C.byref(nA)), "careful_graph")
+    n = nA.value
+    return OGraph(st.value, ao[: nS.value + 1], il[:n], ol[:n], w[:n], ns[:n], fin[: nS.value])
+
+
+def _cfg(beam, retry_beam, max_active=2**31 - 1, min_active=20, beam_delta=0.5, hash_ratio=2.0):
+    return AlignConfig(beam, retry_beam, 0, max_active, min_active, beam_delta, hash_ratio)
+
+
+def align_utterance(g: OGraph, m: OModel, id2pdf, feats, acoustic_scale=1.0, beam=200.0, retry_beam=0.0, **kw):
+    id2pdf = np.ascontiguousarray(id2pdf, np.int32); feats = np.ascontiguousarray(feats, f32)
+    T = feats.shape[0]
+    ali = np.zeros(max(T, 1), np.int32); words = np.zeros(T + g.final.shape[0] + 8, np.int32)
+    nw = C.c_int32(); like = C.c_float(); status = C.c_int32(); st = AlignStats()
+    cfg = _cfg(beam, retry_beam, **kw)
+    rc = lib().orc_align_utterance(C.byref(cfg), C.c_float(acoustic_scale), C.byref(g.c), C.byref(m.c),
+                                   _p(id2pdf, C.c_int32), id2pdf.shape[0] - 1, T, _p(feats, C.c_float),
+                                   _p(ali, C.c_int32), _p(words, C.c_int32), words.shape[0], C.byref(nw),
+                                   C.byref(like), C.byref(status), C.byref(st))
+    _chk(rc, "align_utterance")
+    ok = (status.value & 1) == 0
+    return {"ali": ali[:T] if ok else np.zeros(0, np.int32), "words": words[: nw.value], "like": like.value,
+            "status": status.value, "loglike_evals": st.loglike_evals, "tokens_expanded": st.tokens_expanded}
+
+
+def align_utterance_ll(g: OGraph, id2pdf, T, pdfs, ll, acoustic_scale=1.0, beam=200.0, retry_beam=0.0, **kw):
+    id2pdf = np.ascontiguousarray(id2pdf, np.int32); pdfs = np.ascontiguousarray(pdfs, np.int32)
+    ll = np.ascontiguousarray(ll, f32)
+    ali = np.zeros(max(T, 1), np.int32); words = np.zeros(T + g.final.shape[0] + 8, np.int32)
+    nw = C.c_int32(); like = C.c_float(); status = C.c_int32(); st = AlignStats()
+    cfg = _cfg(beam, retry_beam, **kw)
+    rc = lib().orc_align_utterance_ll(C.byref(cfg), C.c_float(acoustic_scale), C.byref(g.c), _p(id2pdf, C.c_int32),
+                                      id2pdf.shape[0] - 1, T, pdfs.shape[0], _p(pdfs, C.c_int32), _p(ll, C.c_float),
+                                      C.c_int64(ll.shape[1] if ll.ndim == 2 else T), _p(ali, C.c_int32),
+                                      _p(words, C.c_int32), words.shape[0], C.byref(nw), C.byref(like),
+                                      C.byref(status), C.byref(st))
+    _chk(rc, "align_utterance_ll")
+    ok = (status.value & 1) == 0
+    return {"ali": ali[:T] if ok else np.zeros(0, np.int32), "words": words[: nw.value], "like": like.value,
+            "status": status.value}
+
+
+def exact_viterbi_ll(g: OGraph, id2pdf, T, pdfs, ll, acoustic_scale=1.0):
+    id2pdf = np.ascontiguousarray(id2pdf, np.int32); pdfs = np.ascontiguousarray(pdfs, np.int32)
+    ll = np.ascontiguousarray(ll, f32)
+    ali = np.zeros(max(T, 1), np.int32); bc = C.c_double(); status = C.c_int32()
+    rc = lib().orc_exact_viterbi_ll(C.c_float(acoustic_scale), C.byref(g.c), _p(id2pdf, C.c_int32),
+                                    id2pdf.shape[0] - 1, T, pdfs.shape[0], _p(pdfs, C.c_int32), _p(ll, C.c_float),
+                                    C.c_int64(ll.shape[1] if ll.ndim == 2 else T), _p(ali, C.c_int32), C.byref(bc),
+                                    C.byref(status))
+    _chk(rc, "exact_viterbi_ll")
+    return {"ali": ali[:T], "cost": bc.value, "status": status.value}
+
+
+class OAccs:
+    def __init__(self, sumG, D, num_tids):
+        self.occ = np.zeros(sumG, np.float64); self.mean_acc = np.zeros((sumG, D), np.float64)
+        self.var_acc = np.zeros((sumG, D), np.float64); self.trans_acc = np.zeros(num_tids + 1, np.float64)
+        self.c = Accs(_p(self.occ, C.c_double), _p(self.mean_acc, C.c_double), _p(self.var_acc, C.c_double),
+                      _p(self.trans_acc, C.c_double), 0.0, 0.0)
+
+    @property
+    def total_frames(self):
+        return self.c.total_frames
+
+    @property
+    def total_log_like(self):
+        return self.c.total_log_like
+
+
+def acc_stats_ali(m: OModel, id2pdf, feats, ali, accs: OAccs, weight=1.0):
+    id2pdf = np.ascontiguousarray(id2pdf, np.int32); feats = np.ascontiguousarray(feats, f32)
+    ali = np.ascontiguousarray(ali, np.int32)
+    ll = C.c_double()
+    _chk(lib().orc_acc_stats_ali(C.byref(m.c), _p(id2pdf, C.c_int32), id2pdf.shape[0] - 1, feats.shape[0],
+                                 _p(feats, C.c_float), _p(ali, C.c_int32), C.c_float(weight), C.byref(accs.c),
+                                 C.byref(ll)), "acc_stats_ali")
+    return ll.value
+
+
+def mle_diag_gmm_update(weights, means_invvars, inv_vars, occ, mean_acc, var_acc, acc_flags=0xF, flags=0x7,
+                        min_gaussian_weight=1e-5, min_gaussian_occupancy=10.0, min_variance=1e-3, remove=True):
+    w = np.array(weights, f32, copy=True); miv = np.array(means_invvars, f32, copy=True)
+    iv = np.array(inv_vars, f32, copy=True); gc = np.zeros_like(w)
+    occ = np.ascontiguousarray(occ, np.float64); ma = np.ascontiguousarray(mean_acc, np.float64)
+    va = np.ascontiguousarray(var_acc, np.float64)
+    o = MleOpts(min_gaussian_weight, min_gaussian_occupancy, min_variance, int(remove))
+    G = C.c_int32(w.shape[0]); oc = C.c_float(); cnt = C.c_float(); fe = C.c_int32(); fg = C.c_int32(); rm = C.c_int32()
+    _chk(lib().orc_mle_diag_gmm_update(C.byref(o), C.byref(G), miv.shape[1], _p(occ, C.c_double), _p(ma, C.c_double),
+                                       _p(va, C.c_double), C.c_uint16(acc_flags), C.c_uint16(flags), _p(w, C.c_float),
+                                       _p(gc, C.c_float), _p(miv, C.c_float), _p(iv, C.c_float), C.byref(oc),
+                                       C.byref(cnt), C.byref(fe), C.byref(fg), C.byref(rm)), "mle_diag_gmm_update")
+    g = G.value
+    return {"weights": w[:g], "gconsts": gc[:g], "means_invvars": miv[:g], "inv_vars": iv[:g], "obj_change": oc.value,
+            "count": cnt.value, "floored_elems": fe.value, "floored_gauss": fg.value, "removed": rm.value}
+
+
+def transition_mle_update(state2id, self_loop_of, stats, log_probs, nsl, floor=0.01, mincount=5.0):
+    s2i = np.ascontiguousarray(state2id, np.int32); slo = np.ascontiguousarray(self_loop_of, np.int32)
+    st = np.ascontiguousarray(stats, np.float64); lp = np.array(log_probs, f32, copy=True); ns = np.array(nsl, f32, copy=True)
+    oi = C.c_float(); cnt = C.c_float()
+    _chk(lib().orc_transition_mle_update(slo.shape[0] - 1, _p(s2i, C.c_int32), _p(slo, C.c_int32), _p(st, C.c_double),
+                                         C.c_float(floor), C.c_float(mincount), _p(lp, C.c_float), _p(ns, C.c_float),
+                                         C.byref(oi), C.byref(cnt)), "transition_mle_update")
+    return lp, ns, oi.value, cnt.value
+
+
+def augment_gmm_flags(flags):
+    return int(lib().orc_augment_gmm_flags(flags))

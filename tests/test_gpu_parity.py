@@ -1,0 +1,139 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star: "integer alignments bit-exact, accumulated stats and log-likelihoods
+within a stated fp32 tolerance"):
+  * log-likes: |gpu - exact64| <= 1e-5 + 1e-6*B, B = max_g(|gconst| + sum|M x| + 0.5 sum|V x^2|):
+    fp32 rounding of a 2D-term sum scales with the magnitude of its terms, not of the result;
+    at D=40 this is ~3e-4, the same order as the 1e-4 the reference's own tests accept
+    (python/tests/test_diag_gmm.py:342-349).  The oracle (sequential fp32 sums) must meet the
+    same bound, and GPU vs oracle twice it.
+  * alignments: bit-exact when both sides read the SAME score matrix
+  * statistics: rtol 2e-5 on occ / mean / var accumulators, transition counts exact
+"""
+import numpy as np
+import pytest
+
+from helpers import build, exact_loglikes, oracle_graph, utt_feats
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LL_ATOL, LL_RTOL = 1e-5, 1e-6
+
+
+def _device(ctx, m, gc, ut, cost):
+    from kaldi_hmm_gmm_amd import DeviceModel, DeviceTransitions, UtteranceSet
+
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    tm.set_trans_cost(cost)
+    us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
+    return dm, tm, us
+
+
+@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, False), (60, 32, 40, True), (30, 64, 40, False),
+                                          (24, 20, 13, True), (12, 128, 80, False)])
+def test_loglikes_vs_oracle(ctx, P, G, D, ragged):
+    m, gc, om, ut, cost = build(P, G, D, n_utt=6, seed=P + G, ragged=ragged, max_phones=5)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    got = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    worst = 0.0
+    for u in range(us.n_utt):
+        pl = pdfs[poff[u]: poff[u + 1]]
+        want = orc.loglikes_matrix(om, utt_feats(ut, u), pl)
+        assert got[u].shape == want.shape
+        exact, bound = exact_loglikes(m, gc, utt_feats(ut, u), pl)
+        tol = LL_ATOL + LL_RTOL * bound
+        err = np.abs(got[u] - exact)
+        worst = max(worst, float((err / tol).max()))
+        assert (err <= tol).all(), f"utt {u}: gpu vs exact max err {err.max()}"
+        assert (np.abs(want - exact) <= tol).all(), "oracle itself outside the fp32 bound"
+        assert (np.abs(got[u] - want) <= 2 * tol).all()
+    print("worst err/tol", worst)
+
+
+def test_loglikes_fma_order_bitwise_gemm(ctx):
+    """The MFMA contraction is bit-for-bit the k-ordered fmaf chain the oracle restates; only
+    exp/log differ, so with G == 1 (log-sum-exp of one term == that term) results are bit-equal."""
+    m, gc, om, ut, cost = build(30, 1, 40, n_utt=3, seed=5)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    got = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    for u in range(us.n_utt):
+        f = utt_feats(ut, u)
+        for j, p in enumerate(pdfs[poff[u]: poff[u + 1]]):
+            g0 = m.gauss_off[p]
+            for t in (0, f.shape[0] // 2, f.shape[0] - 1):
+                v = orc.loglikes(gc[g0:g0 + 1], m.means_invvars[g0:g0 + 1], m.inv_vars[g0:g0 + 1], f[t], fma_order=True)
+                assert got[u][j, t] == v[0]
+
+
+@pytest.mark.parametrize("beam,retry", [(200.0, 0.0), (6.0, 40.0), (1.0, 3.0)])
+def test_align_bit_exact_on_same_scores(ctx, beam, retry):
+    """K2 in isolation: feed the oracle's log-likes to the HIP Viterbi; alignment, words and
+    status must equal the line-faithful FasterDecoder's exactly, `like` to float rounding."""
+    m, gc, om, ut, cost = build(45, 4, 20, n_utt=40, seed=11, max_phones=7)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    poff, pdfs = us.pdf_lists()
+    mats = [orc.loglikes_matrix(om, utt_feats(ut, u), pdfs[poff[u]: poff[u + 1]]) for u in range(us.n_utt)]
+    us.upload_loglikes(mats)
+    res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1)
+    nfallback = 0
+    for u in range(us.n_utt):
+        g = oracle_graph(ut, u, cost)
+        T = int(ut.frame_off[u + 1] - ut.frame_off[u])
+        want = orc.align_utterance_ll(g, m.id2pdf, T, pdfs[poff[u]: poff[u + 1]], mats[u], acoustic_scale=0.1,
+                                      beam=beam, retry_beam=retry)
+        st = int(res["status"][u])
+        nfallback += (st & 8) != 0
+        assert (st & 3) == (want["status"] & 3), (u, st, want["status"])
+        a = res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]]
+        if want["status"] & 1:
+            assert (a == 0).all()
+        else:
+            assert (a == want["ali"]).all(), f"utt {u} differs (status {st})"
+            assert res["like"][u] == pytest.approx(want["like"], rel=1e-6, abs=1e-4)
+    print(f"beam {beam}: {nfallback}/{us.n_utt} utterances used the faithful-decoder kernel")
+
+
+def test_align_end_to_end(ctx):
+    """K1 + K2 against oracle GMM decodable + FasterDecoder: identical alignments on this
+    fixture (well separated models), `like` within the log-like tolerance."""
+    m, gc, om, ut, cost = build(60, 8, 40, n_utt=16, seed=3, max_phones=6)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    res = us.align(tm, acoustic_scale=0.1)
+    for u in range(us.n_utt):
+        g = oracle_graph(ut, u, cost)
+        want = orc.align_utterance(g, om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1)
+        a = res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]]
+        assert int(res["status"][u]) & 1 == 0 and want["status"] == 0
+        assert (a == want["ali"]).all()
+        assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
+
+
+@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (12, 128, 80, False)])
+def test_acc_stats_vs_oracle(ctx, P, G, D, ragged):
+    from kaldi_hmm_gmm_amd import DeviceAccs
+
+    m, gc, om, ut, cost = build(P, G, D, n_utt=12, seed=7, ragged=ragged, max_phones=5)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.upload_ali(ut.ref_ali)
+    accs = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs, weight=1.0)
+    got = accs.download()
+    oa = orc.OAccs(int(m.gauss_off[-1]), D, m.num_tids)
+    tot = 0.0
+    for u in range(us.n_utt):
+        tot += orc.acc_stats_ali(om, m.id2pdf, utt_feats(ut, u), ut.ref_ali[ut.frame_off[u]: ut.frame_off[u + 1]], oa)
+    assert (got["trans_acc"] == oa.trans_acc).all()
+    assert got["trans_acc"].sum() == ut.frame_off[-1]        # scripts/test_gmm_acc_stats_ali.py:106
+    assert got["total_frames"] == oa.total_frames
+    assert got["total_log_like"] == pytest.approx(oa.total_log_like, rel=2e-6)
+    np.testing.assert_allclose(got["occ"], oa.occ, rtol=2e-5, atol=1e-6)
+    scale = np.abs(oa.mean_acc).max()
+    np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
