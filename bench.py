@@ -104,7 +104,10 @@ def main():
     feats = synth.sample_feats_torch(model, ut.frame_pdf, args.seed + 2000 + rank, dev)
     torch.cuda.synchronize()
 
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-null) HIP stream shared by torch (events, RCCL) and the khg context
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx = Context(local, stream=stream.cuda_stream)
     dm = DeviceModel(ctx, model.gauss_off, gc, model.means_invvars, model.inv_vars)
     tm = DeviceTransitions(ctx, model.id2pdf)

@@ -41,6 +41,11 @@ int khg_version(void);
 int khg_ctx_create(int device, void *stream, khg_ctx **out);
 int khg_ctx_destroy(khg_ctx *ctx);
 int khg_ctx_sync(khg_ctx *ctx);
+/* Measurement aid: when on, every kernel launch is bracketed by HIP events on the
+ * context's stream; khg_ctx_get_timings drains (name, ms) pairs, names '\n'-separated. */
+int khg_ctx_set_timing(khg_ctx *ctx, int on);
+int khg_ctx_get_timings(khg_ctx *ctx, char *names, int64_t names_cap, float *ms, int32_t cap,
+                        int32_t *n_out);
 
 /* ---- acoustic model ------------------------------------------------------------------- */
 /* AmDiagGmm (csrc/am-diag-gmm.h:96) as flat ragged arrays: pdf p owns Gaussians

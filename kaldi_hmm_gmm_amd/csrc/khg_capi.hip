@@ -31,11 +31,26 @@ extern "C" int khg_version(void) { return 100; }
       return khg_set_error(KHG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
   } while (0)
 
+struct khg_timing { std::string name; hipEvent_t e0, e1; };
 struct khg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int32_t* err_flag_d = nullptr;
+  bool timing = false;
+  std::vector<khg_timing> timings;
+};
+// scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled)
+struct KernelTimer {
+  khg_ctx* c; size_t idx = 0; bool on;
+  KernelTimer(khg_ctx* ctx, const char* name) : c(ctx), on(ctx->timing) {
+    if (!on) return;
+    khg_timing t; t.name = name;
+    (void)hipEventCreate(&t.e0); (void)hipEventCreate(&t.e1);
+    (void)hipEventRecord(t.e0, c->stream);
+    c->timings.push_back(t); idx = c->timings.size() - 1;
+  }
+  ~KernelTimer() { if (on) (void)hipEventRecord(c->timings[idx].e1, c->stream); }
 };
 
 template <class T>
@@ -82,6 +97,29 @@ extern "C" int khg_ctx_destroy(khg_ctx* c) {
   DEVFREE(c->err_flag_d);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return KHG_OK;
+}
+extern "C" int khg_ctx_set_timing(khg_ctx* c, int on) {
+  if (!c) return khg_set_error(KHG_E_ARG, "ctx is NULL");
+  c->timing = on != 0;
+  return KHG_OK;
+}
+// drains the recorded (kernel name, milliseconds) pairs; names are '\n'-separated
+extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, float* ms, int32_t cap, int32_t* n_out) {
+  if (!c || !n_out) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int n = 0; std::string all;
+  for (auto& t : c->timings) {
+    float v = 0.0f;
+    (void)hipEventElapsedTime(&v, t.e0, t.e1);
+    if (n < cap && ms) ms[n] = v;
+    all += t.name; all += '\n';
+    (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1);
+    ++n;
+  }
+  c->timings.clear();
+  if (names && names_cap > 0) { size_t k = std::min<size_t>(all.size(), (size_t)names_cap - 1); memcpy(names, all.data(), k); names[k] = 0; }
+  *n_out = n;
   return KHG_OK;
 }
 extern "C" int khg_ctx_sync(khg_ctx* c) {
@@ -459,6 +497,7 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d; a.D = m->D;
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
+    KernelTimer kt(ctx, "k1_loglikes");
     if (m->KQ == 10) launch_k1<10, 3, 2>(a, u->n_chunks, aligned, ctx->stream);
     else launch_k1<20, 4, 1>(a, u->n_chunks, aligned, ctx->stream);
     HIPCHK(hipGetLastError());
@@ -550,7 +589,10 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   a.max_active = cfg->max_active; a.min_active = cfg->min_active;
   a.max_states = u->max_states; a.max_inarcs = u->max_inarcs;
   const size_t S = (size_t)u->max_states, A = (size_t)u->max_inarcs;
-  size_t lds_dp = 16 * S + 16 + 4 * (S + 1) + 12 * A + 16 + 64;
+  size_t max_npdf = 0;
+  for (int i = 0; i < u->n_utt; ++i) max_npdf = std::max<size_t>(max_npdf, (size_t)(u->pdf_off[i + 1] - u->pdf_off[i]));
+  // arcs | cur | nxt | in_off | max(score block, back-pointer block)
+  size_t lds_dp = 16 * A + 16 * S + 4 * (S + 1) + 16 + std::max<size_t>(4 * K2_FB * (max_npdf | 1), (K2_FB + 1) * S) + 64;
   size_t HB = std::max<size_t>(2 * S, 1000);
   size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
   if (lds_dp > 160 * 1024 || lds_f > 160 * 1024)
@@ -558,10 +600,16 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
                                                 std::to_string(u->max_states) + " states, " + std::to_string(u->max_inarcs) + " arcs)");
   if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
   if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-  const int nthr = S <= 256 ? 64 : (S <= 512 ? 128 : 256);
-  hipLaunchKernelGGL(k2_viterbi_dp, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+  const int nthr = 64;  // one wave per utterance
+  {
+    KernelTimer kt(ctx, "k2_viterbi_dp");
+    hipLaunchKernelGGL(k2_viterbi_dp, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+  }
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, ctx->stream, a);
+  {
+    KernelTimer kt(ctx, "k2_viterbi_faithful");
+    hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, ctx->stream, a);
+  }
   HIPCHK(hipGetLastError());
   u->ali_valid = true;
   rc = check_err_flag(ctx, "khg_align");  // synchronises
@@ -671,18 +719,26 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
   a.weight = weight; a.err_flag = ctx->err_flag_d;
   if (u->N > 0) {
     const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
-    hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+    {
+      KernelTimer kt(ctx, "k3_bucket");
+      hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
+      hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+    }
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const int Gp = (maxG + 63) & ~63;
-    const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)m->D + Gp);
+    const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + Gp);
     if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : (const void*)k3_accumulate<20>;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
     const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
-    hipLaunchKernelGGL(k3_accumulate, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+    {
+      KernelTimer kt(ctx, "k3_accumulate");
+      if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+      else hipLaunchKernelGGL(k3_accumulate<20>, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+    }
     HIPCHK(hipGetLastError());
   }
   return check_err_flag(ctx, "khg_acc_stats");

@@ -32,6 +32,19 @@ class Context:
     def sync(self):
         check(lib.khg_ctx_sync(self.h))
 
+    def set_timing(self, on: bool):
+        check(lib.khg_ctx_set_timing(self.h, int(on)))
+
+    def timings(self):
+        """-> list of (kernel name, ms) recorded since the last call (HIP events on the ctx stream)."""
+        cap = 4096
+        names = C.create_string_buffer(1 << 16)
+        ms = np.zeros(cap, np.float32)
+        n = C.c_int32()
+        check(lib.khg_ctx_get_timings(self.h, names, len(names), ptr(ms, C.c_float), cap, C.byref(n)))
+        nm = names.value.decode().split("\n")[: n.value]
+        return list(zip(nm, ms[: n.value].tolist()))
+
     def close(self):
         if self.h:
             lib.khg_ctx_destroy(self.h)
