@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -150,7 +151,7 @@ struct khg_model {
   float* wimg_d = nullptr;
   int32_t* pdf_tile_off_d = nullptr;
   int32_t* gauss_off_d = nullptr;
-  float *gconsts_d = nullptr, *miv_d = nullptr, *iv_d = nullptr;
+  float *gconsts_d = nullptr, *miv_d = nullptr, *iv_d = nullptr, *nhiv_d = nullptr;
 };
 
 extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_t* gauss_off,
@@ -197,6 +198,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
   if (!rc) { tmp.assign(gconsts, gconsts + m->sumG); rc = dev_upload(ctx, &m->gconsts_d, tmp); }
   if (!rc) { tmp.assign(miv, miv + m->sumG * D); rc = dev_upload(ctx, &m->miv_d, tmp); }
   if (!rc) { tmp.assign(iv, iv + m->sumG * D); rc = dev_upload(ctx, &m->iv_d, tmp); }
+  if (!rc) { for (auto& x : tmp) x = -0.5f * x; rc = dev_upload(ctx, &m->nhiv_d, tmp); }
   if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
   if (rc) { khg_model_destroy(m); return rc; }
   *out = m;
@@ -205,7 +207,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   DEVFREE(m->wimg_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
-  DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d);
+  DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d);
   delete m;
   return KHG_OK;
 }
@@ -258,7 +260,8 @@ struct khg_utts {
   bool has_graphs = false;
   std::vector<int64_t> frame_off, state_off, pdf_off, ll_off, bp_off, path_off, words_off;
   std::vector<int32_t> pdfs;
-  int32_t max_states = 0, max_inarcs = 0;
+  int32_t max_states = 0, max_inarcs = 0, max_indeg = 0;
+  bool has_eps = false;
   // device
   const float* feats_d = nullptr; bool own_feats = false;
   int64_t *frame_off_d = nullptr, *state_off_d = nullptr, *pdf_off_d = nullptr, *ll_off_d = nullptr;
@@ -339,6 +342,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
       const int64_t T = frame_off[i + 1] - frame_off[i];
       if (S < 0 || A < 0) return fail(KHG_E_ARG, "khg_utts_create: offsets not monotone");
       if (start[i] >= S) return fail(KHG_E_ARG, "khg_utts_create: start state out of range");
+      if (S > 65535) return fail(KHG_E_UNSUPPORTED, "khg_utts_create: more than 65535 states in one decoding graph");
       u->max_states = std::max<int64_t>(u->max_states, S);
       u->max_inarcs = std::max<int64_t>(u->max_inarcs, A);
       // pdf list of this utterance = distinct id2pdf[ilabel] over its arcs
@@ -348,12 +352,13 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
         int l = ilabel[a];
         if (l < 0 || l > tm->num_tids)
           return fail(KHG_E_RUNTIME, "AddTransitionProbs: invalid symbol " + std::to_string(l) + " on graph input side.");
-        if (l >= 1) tmp_pdfs.push_back(tm->id2pdf[l]);
+        if (l >= 1) tmp_pdfs.push_back(tm->id2pdf[l]); else u->has_eps = true;
         if (nextstate[a] < 0 || nextstate[a] >= S) return fail(KHG_E_ARG, "khg_utts_create: nextstate out of range");
         if (olabel[a] != 0) ++nwords;
       }
       std::sort(tmp_pdfs.begin(), tmp_pdfs.end());
       tmp_pdfs.erase(std::unique(tmp_pdfs.begin(), tmp_pdfs.end()), tmp_pdfs.end());
+      if (tmp_pdfs.size() > 32767) return fail(KHG_E_UNSUPPORTED, "khg_utts_create: more than 32767 distinct pdfs on one decoding graph");
       u->pdf_off[i + 1] = u->pdf_off[i] + (int64_t)tmp_pdfs.size();
       u->pdfs.insert(u->pdfs.end(), tmp_pdfs.begin(), tmp_pdfs.end());
       // in-arc CSR: stable bucketing by destination (ties in the DP then resolve to the lowest
@@ -362,6 +367,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
       in_off[s0] = a0;
       for (int64_t s = 0; s < S; ++s) {
         if (in_off[s0 + s + 1] > 254) return fail(KHG_E_UNSUPPORTED, "khg_utts_create: a state has more than 254 incoming arcs");
+        u->max_indeg = std::max<int32_t>(u->max_indeg, (int32_t)in_off[s0 + s + 1]);
         in_off[s0 + s + 1] += in_off[s0 + s];
       }
       cursor.assign(S, 0);
@@ -380,7 +386,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
           out_inidx[a] = (int32_t)(pos - a0);
         }
       }
-      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * S;
+      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 256);  // >= 256 B per layer: room for the packed fast-path format
       u->path_off[i + 1] = u->path_off[i] + T + S + 8;
       u->words_off[i + 1] = u->words_off[i] + nwords;
     }
@@ -584,6 +590,9 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   a.path = u->path_d; a.path_off = u->path_off_d;
   a.ali = u->ali_d; a.words = u->words_d; a.words_off = u->words_off_d; a.num_words = u->num_words_d;
   a.like = u->like_d; a.status = u->status_d; a.err_flag = ctx->err_flag_d;
+  a.prof = nullptr;
+  const bool k2prof = getenv("KHG_K2_PROF") != nullptr;
+  if (k2prof) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&a.prof), sizeof(long long) * 8 * (size_t)u->n_utt)); HIPCHK(hipMemset(a.prof, 0, sizeof(long long) * 8 * (size_t)u->n_utt)); }
   a.beam = cfg->beam; a.retry_beam = cfg->retry_beam; a.acoustic_scale = cfg->acoustic_scale;
   a.beam_delta = cfg->beam_delta; a.hash_ratio = cfg->hash_ratio;
   a.max_active = cfg->max_active; a.min_active = cfg->min_active;
@@ -591,19 +600,31 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const size_t S = (size_t)u->max_states, A = (size_t)u->max_inarcs;
   size_t max_npdf = 0;
   for (int i = 0; i < u->n_utt; ++i) max_npdf = std::max<size_t>(max_npdf, (size_t)(u->pdf_off[i + 1] - u->pdf_off[i]));
-  // arcs | cur | nxt | in_off | max(score block, back-pointer block)
-  size_t lds_dp = 16 * A + 16 * S + 4 * (S + 1) + 16 + std::max<size_t>(4 * K2_FB * (max_npdf | 1), (K2_FB + 1) * S) + 64;
+  // threads: one destination state each (up to 1024), KS states per thread beyond that
+  const int nthr = (int)std::min<size_t>(1024, (S + 63) / 64 * 64);
+  const size_t nwave = nthr / 64;
+  const bool fast = !u->has_eps && u->max_indeg <= 3 && S <= 4096;   // whole batch takes the register-resident path
+  const int KSsel = !fast ? 0 : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4));
+  const size_t NSl = fast ? KSsel : 1;
+  const size_t LBmax = fast ? 16 * nwave * NSl : ((S + 15) & ~size_t(15));
+  // cur | nxt | packed bp block (fast) | reductions | arcs | in_off | wave minima/counts | flags | [align] | max(score block (generic), trace-back block)
+  size_t lds_dp = 16 * S + (fast ? 8 * K2_FB * nwave * NSl * 2 : 0) + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
+                  std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), (K2_FB + 1) * LBmax) + 64;
   size_t HB = std::max<size_t>(2 * S, 1000);
   size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
   if (lds_dp > 160 * 1024 || lds_f > 160 * 1024)
     return khg_set_error(KHG_E_UNSUPPORTED, "khg_align: decoding graph too large for the LDS-resident Viterbi kernels (" +
                                                 std::to_string(u->max_states) + " states, " + std::to_string(u->max_inarcs) + " arcs)");
-  if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
+  const void* k2fn = KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
+                   : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
+  if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
   if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-  const int nthr = 64;  // one wave per utterance
   {
     KernelTimer kt(ctx, "k2_viterbi_dp");
-    hipLaunchKernelGGL(k2_viterbi_dp, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else if (KSsel == 2) hipLaunchKernelGGL((k2_viterbi_dp<2, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else if (KSsel == 4) hipLaunchKernelGGL((k2_viterbi_dp<4, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
   }
   HIPCHK(hipGetLastError());
   {
@@ -612,6 +633,16 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   }
   HIPCHK(hipGetLastError());
   u->ali_valid = true;
+  if (k2prof) {  // diagnostics: average s_memtime ticks per phase of k2_viterbi_dp
+    std::vector<long long> pr(8 * (size_t)u->n_utt);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(pr.data(), a.prof, pr.size() * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(a.prof);
+    double ph[4] = {0, 0, 0, 0}, sT = 0, sS = 0, sf = 0; int n = 0;
+    for (int i = 0; i < u->n_utt; ++i) if (pr[i * 8 + 4]) { for (int k = 0; k < 4; ++k) ph[k] += (double)(pr[i * 8 + k + 1] - pr[i * 8 + k]); sT += pr[i * 8 + 5]; sS += pr[i * 8 + 6]; sf += pr[i * 8 + 7]; ++n; }
+    if (n) fprintf(stderr, "[KHG_K2_PROF] %d utts, avg T %.1f S %.1f fast %.2f threads %d lds %zu | ticks: setup %.0f forward %.0f traceback %.0f replay %.0f\n",
+                   n, sT / n, sS / n, sf / n, nthr, lds_dp, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+  }
   rc = check_err_flag(ctx, "khg_align");  // synchronises
   if (rc) return rc;
   if (ali_h) HIPCHK(hipMemcpyAsync(ali_h, u->ali_d, sizeof(int32_t) * (size_t)u->N, hipMemcpyDeviceToHost, ctx->stream));
@@ -712,7 +743,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
   K3Args a;
   a.feats = u->feats_d; a.ali = u->ali_d; a.id2pdf = tm->id2pdf_d; a.num_tids = tm->num_tids;
   a.N = u->N; a.P = m->P; a.D = m->D;
-  a.gauss_off = m->gauss_off_d; a.gconsts = m->gconsts_d; a.means_invvars = m->miv_d; a.inv_vars = m->iv_d;
+  a.gauss_off = m->gauss_off_d; a.gconsts = m->gconsts_d; a.means_invvars = m->miv_d; a.inv_vars = m->iv_d; a.nhalf_inv_vars = m->nhiv_d;
   a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
   a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
   a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
@@ -727,8 +758,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     }
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
-    const int Gp = (maxG + 63) & ~63;
-    const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + Gp);
+    const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + (maxG | 1) + 4);
     if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
     const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : (const void*)k3_accumulate<20>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
