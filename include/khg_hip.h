@@ -40,6 +40,9 @@ int khg_version(void);
  * context create its own non-blocking stream. */
 int khg_ctx_create(int device, void *stream, khg_ctx **out);
 int khg_ctx_destroy(khg_ctx *ctx);
+/* Waits for the stream and reports kernel-side errors deferred by the asynchronous entry points
+ * (khg_loglikes, khg_align without host outputs, khg_acc_stats): KHG_E_RUNTIME where the reference
+ * would have thrown (NaN/Inf log-likelihood, pdf-id out of range). */
 int khg_ctx_sync(khg_ctx *ctx);
 /* Measurement aid: when on, every kernel launch is bracketed by HIP events on the
  * context's stream; khg_ctx_get_timings drains (name, ms) pairs, names '\n'-separated. */

@@ -1,4 +1,21 @@
-"""MI355X-native HMM-GMM EM hot path (align + acc-stats + M-step) behind the reference's names."""
+"""kaldi_hmm_gmm_amd -- MI355X-native HMM-GMM EM hot path (K1 log-likes on fp32 MFMA, K2 Viterbi
+forced alignment, K3 sufficient statistics, host M-step) behind the names of the reference's
+pybind11 module `kaldi_hmm_gmm` (python/kaldi_hmm_gmm/__init__.py) and of its scripts/*.py.
+
+Importing this package loads libkhg_hip.so; there is no CPU fallback."""
 from . import _lib  # noqa: F401  (fails loudly when libkhg_hip.so is missing)
+from ._lib import KhgError  # noqa: F401
+from .align import (AlignConfig, DecodableAmDiagGmmScaled, DecodableAmDiagGmmUnmapped, FasterDecoderOptions,  # noqa: F401
+                    add_transition_probs, align_batch, align_utterance_wrapper)
+from .context_dep import ContextDependency, monophone_context_dependency, monophone_context_dependency_shared  # noqa: F401
 from .device import (ALIGN_DONE, ALIGN_ERROR, ALIGN_EXACT_DP, ALIGN_FALLBACK, ALIGN_RETRIED, Context, DeviceAccs,  # noqa: F401
                      DeviceModel, DeviceTransitions, UtteranceSet)
+from .diag_gmm import AmDiagGmm, DiagGmm  # noqa: F401
+from .fst import StdArc, StdVectorFst, modify_graph_for_careful_alignment  # noqa: F401
+from .hmm_topology import HmmState, HmmTopology  # noqa: F401
+from .mle import (AccumAmDiagGmm, AccumDiagGmm, GmmUpdateFlags, MleDiagGmmOptions, augment_gmm_flags,  # noqa: F401
+                  get_split_targets, gmm_flags_to_str, ml_objective, mle_am_diag_gmm_update, mle_diag_gmm_update,
+                  str_to_gmm_flags)
+from .scripts import (gmm_acc_stats_ali, gmm_acc_stats_ali_batch, gmm_align_compiled, gmm_align_compiled_batch,  # noqa: F401
+                      gmm_boost_silence, gmm_est, gmm_init_mono)
+from .transition_model import MleTransitionUpdateConfig, TransitionModel, TransitionModelTuple, get_pdfs_for_phones  # noqa: F401

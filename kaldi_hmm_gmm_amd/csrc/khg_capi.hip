@@ -36,6 +36,9 @@ struct khg_timing { std::string name; hipEvent_t e0, e1; };
 struct khg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  static constexpr int NSIDE = 4;
+  hipStream_t sides[NSIDE] = {nullptr, nullptr, nullptr, nullptr};  // the serial faithful-decoder kernels run here, beside the main stream's next K1
+  int next_side = 0;
   bool own_stream = false;
   int32_t* err_flag_d = nullptr;
   bool timing = false;
@@ -43,15 +46,15 @@ struct khg_ctx {
 };
 // scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled)
 struct KernelTimer {
-  khg_ctx* c; size_t idx = 0; bool on;
-  KernelTimer(khg_ctx* ctx, const char* name) : c(ctx), on(ctx->timing) {
+  khg_ctx* c; size_t idx = 0; bool on; hipStream_t s;
+  KernelTimer(khg_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx), on(ctx->timing), s(st ? st : ctx->stream) {
     if (!on) return;
     khg_timing t; t.name = name;
     (void)hipEventCreate(&t.e0); (void)hipEventCreate(&t.e1);
-    (void)hipEventRecord(t.e0, c->stream);
+    (void)hipEventRecord(t.e0, s);
     c->timings.push_back(t); idx = c->timings.size() - 1;
   }
-  ~KernelTimer() { if (on) (void)hipEventRecord(c->timings[idx].e1, c->stream); }
+  ~KernelTimer() { if (on) (void)hipEventRecord(c->timings[idx].e1, s); }
 };
 
 template <class T>
@@ -86,6 +89,7 @@ extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
   c->device = device;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
   else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  for (auto& s : c->sides) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   int rc = dev_alloc(&c->err_flag_d, 1);
   if (rc) { delete c; return rc; }
   HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
@@ -95,8 +99,10 @@ extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
 extern "C" int khg_ctx_destroy(khg_ctx* c) {
   if (!c) return KHG_OK;
   (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->sides) (void)hipStreamSynchronize(s);
   DEVFREE(c->err_flag_d);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  for (auto& s : c->sides) (void)hipStreamDestroy(s);
   delete c;
   return KHG_OK;
 }
@@ -109,6 +115,7 @@ extern "C" int khg_ctx_set_timing(khg_ctx* c, int on) {
 extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, float* ms, int32_t cap, int32_t* n_out) {
   if (!c || !n_out) return khg_set_error(KHG_E_ARG, "bad arguments");
   HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& s : c->sides) HIPCHK(hipStreamSynchronize(s));
   int n = 0; std::string all;
   for (auto& t : c->timings) {
     float v = 0.0f;
@@ -123,14 +130,15 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
   *n_out = n;
   return KHG_OK;
 }
+static int check_err_flag(khg_ctx* c, const char* where);
 extern "C" int khg_ctx_sync(khg_ctx* c) {
   if (!c) return khg_set_error(KHG_E_ARG, "ctx is NULL");
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return KHG_OK;
+  return check_err_flag(c, "khg_ctx_sync");   // synchronises the stream, then reports deferred kernel errors
 }
 // read-and-clear the device error word; maps bits to the reference's exceptions
 static int check_err_flag(khg_ctx* c, const char* where) {
   int32_t f = 0;
+  for (auto& s : c->sides) HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipMemcpyAsync(&f, c->err_flag_d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (f) {
@@ -278,6 +286,8 @@ struct khg_utts {
   int32_t *ali_d = nullptr, *words_d = nullptr, *num_words_d = nullptr, *status_d = nullptr;
   float* like_d = nullptr;
   bool ali_valid = false;
+  hipEvent_t ev_dp = nullptr, ev_ali = nullptr;   // K2-DP done (main) -> faithful kernel (side) -> alignment complete
+  bool ali_pending = false;
   // K3 scratch
   int32_t *pdf_count_d = nullptr, *pdf_cursor_d = nullptr, *frame_ids_d = nullptr;
   int64_t* pdf_start_d = nullptr; unsigned long long* tid_count_d = nullptr;
@@ -438,6 +448,8 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
+  if (u->ev_dp) (void)hipEventDestroy(u->ev_dp);
+  if (u->ev_ali) (void)hipEventDestroy(u->ev_ali);
   delete u;
   return KHG_OK;
 }
@@ -449,6 +461,12 @@ extern "C" int khg_utts_num_pdfs(const khg_utts* u, int64_t* pdf_off) {
 extern "C" int khg_utts_pdfs(const khg_utts* u, int32_t* pdfs) {
   if (!u || !pdfs) return khg_set_error(KHG_E_ARG, "bad arguments");
   std::copy(u->pdfs.begin(), u->pdfs.end(), pdfs);
+  return KHG_OK;
+}
+
+// the main stream must not touch ali / status / the ll buffer while the side-stream decoder runs
+static int wait_ali(khg_ctx* ctx, khg_utts* u) {
+  if (u->ali_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, u->ev_ali, 0)); u->ali_pending = false; }
   return KHG_OK;
 }
 
@@ -466,7 +484,8 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   if (m->D != u->D) return khg_set_error(KHG_E_RUNTIME, "Dim mismatch: data dim = " + std::to_string(u->D) + " vs. model dim = " + std::to_string(m->D));
   for (int32_t p : u->pdfs)
     if (p < 0 || p >= m->P) return khg_set_error(KHG_E_RUNTIME, "Likely graph/model mismatch, e.g. using wrong HCLG.fst (pdf-id " + std::to_string(p) + ")");
-  int rc = KHG_OK;
+  int rc = wait_ali(ctx, u);
+  if (rc) return rc;
   if (!u->pdf_off_d) {
     rc = dev_upload(ctx, &u->pdf_off_d, u->pdf_off);
     if (!rc) rc = dev_upload(ctx, &u->pdfs_d, u->pdfs);
@@ -528,7 +547,8 @@ extern "C" int khg_loglikes_download(khg_ctx* ctx, const khg_utts* u, float* ll)
 }
 extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
   if (!ctx || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
-  int rc = KHG_OK;
+  int rc = wait_ali(ctx, u);
+  if (rc) return rc;
   if (!u->pdf_off_d) {
     rc = dev_upload(ctx, &u->pdf_off_d, u->pdf_off);
     if (!rc) rc = dev_upload(ctx, &u->pdfs_d, u->pdfs);
@@ -566,7 +586,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   // faster-decoder.cc:24-27
   if (!(cfg->hash_ratio >= 1.0) || !(cfg->max_active > 1) || !(cfg->min_active >= 0 && cfg->min_active < cfg->max_active))
     return khg_set_error(KHG_E_RUNTIME, "FasterDecoderOptions assertion failed");
-  int rc = ensure_ali(ctx, u);
+  int rc = wait_ali(ctx, u);
+  if (!rc) rc = ensure_ali(ctx, u);
   if (rc) return rc;
   if (!u->bp_d) {
     rc = dev_alloc(&u->bp_d, (size_t)u->bp_off[u->n_utt]);
@@ -627,11 +648,18 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     else hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
   }
   HIPCHK(hipGetLastError());
+  if (!u->ev_dp) { HIPCHK(hipEventCreateWithFlags(&u->ev_dp, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&u->ev_ali, hipEventDisableTiming)); }
+  HIPCHK(hipEventRecord(u->ev_dp, ctx->stream));
+  hipStream_t side = ctx->sides[ctx->next_side];
+  ctx->next_side = (ctx->next_side + 1) % khg_ctx::NSIDE;
+  HIPCHK(hipStreamWaitEvent(side, u->ev_dp, 0));
   {
-    KernelTimer kt(ctx, "k2_viterbi_faithful");
-    hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, ctx->stream, a);
+    KernelTimer kt(ctx, "k2_viterbi_faithful", side);
+    hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, side, a);
   }
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(u->ev_ali, side));
+  u->ali_pending = true;
   u->ali_valid = true;
   if (k2prof) {  // diagnostics: average s_memtime ticks per phase of k2_viterbi_dp
     std::vector<long long> pr(8 * (size_t)u->n_utt);
@@ -643,6 +671,9 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     if (n) fprintf(stderr, "[KHG_K2_PROF] %d utts, avg T %.1f S %.1f fast %.2f threads %d lds %zu | ticks: setup %.0f forward %.0f traceback %.0f replay %.0f\n",
                    n, sT / n, sS / n, sf / n, nthr, lds_dp, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
   }
+  if (!ali_h && !like_h && !status_h && !words_h) return KHG_OK;   // asynchronous: errors surface at khg_ctx_sync / downloads
+  rc = wait_ali(ctx, u);
+  if (rc) return rc;
   rc = check_err_flag(ctx, "khg_align");  // synchronises
   if (rc) return rc;
   if (ali_h) HIPCHK(hipMemcpyAsync(ali_h, u->ali_d, sizeof(int32_t) * (size_t)u->N, hipMemcpyDeviceToHost, ctx->stream));
@@ -669,7 +700,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
 
 extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
   if (!ctx || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
-  int rc = ensure_ali(ctx, u);
+  int rc = wait_ali(ctx, u);
+  if (!rc) rc = ensure_ali(ctx, u);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(u->ali_d, ali, sizeof(int32_t) * (size_t)u->N, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -710,6 +742,7 @@ extern "C" int khg_accs_size(const khg_accs* a, int64_t* n) { if (!a || !n) retu
 extern "C" int khg_accs_device_ptr(const khg_accs* a, void** p) { if (!a || !p) return khg_set_error(KHG_E_ARG, "bad arguments"); *p = a->buf_d; return KHG_OK; }
 extern "C" int khg_accs_download(khg_ctx* ctx, const khg_accs* a, double* buf) {
   if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(buf, a->buf_d, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return KHG_OK;
@@ -727,7 +760,8 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
   if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
     return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");
   if (tm->max_pdf >= m->P) return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: transition model refers to pdf-ids the model does not have");
-  int rc = KHG_OK;
+  int rc = wait_ali(ctx, u);
+  if (rc) return rc;
   if (!u->frame_ids_d || u->k3_P != m->P || u->k3_tids != tm->num_tids) {
     DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d); DEVFREE(u->frame_ids_d);
     rc = dev_alloc(&u->pdf_count_d, (size_t)m->P);
@@ -771,5 +805,5 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     }
     HIPCHK(hipGetLastError());
   }
-  return check_err_flag(ctx, "khg_acc_stats");
+  return KHG_OK;   // asynchronous: kernel-side errors surface at khg_ctx_sync / khg_accs_download
 }

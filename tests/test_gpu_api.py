@@ -1,0 +1,322 @@
+"""GPU tests through the reference's own names (they read like python/tests/test_diag_gmm.py,
+test_mle_diag_gmm.py and scripts/test_gmm_*.py) plus the decoder corner cases: forced fallback to the
+order-faithful kernel, epsilon arcs + words, careful mode, exact ties, error / retry statuses."""
+import math
+
+import numpy as np
+import pytest
+
+from graphs import concat, random_graph
+from helpers import build, oracle_graph, utt_feats
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def khg(ctx):
+    import kaldi_hmm_gmm_amd as k
+    from kaldi_hmm_gmm_amd import _gpu
+
+    _gpu.set_default_context(ctx)
+    return k
+
+
+def _gmm(khg, rng, nmix, dim):
+    g = khg.DiagGmm(nmix=nmix, dim=dim)
+    w = rng.random(nmix).astype(np.float32); w /= w.sum()
+    mean = rng.random((nmix, dim)).astype(np.float32)
+    var = (rng.random((nmix, dim)) * 0.9 + 0.1).astype(np.float32)
+    g.set_weights(w); g.set_means(mean); g.set_invvars(1 / var); g.compute_gconsts()
+    return g, w, mean, var
+
+
+def _density(w, mean, var, x):
+    w, mean, var, x = (a.astype(np.float64) for a in (w, mean, var, x))
+    e = np.exp(((x - mean) ** 2 / (-2 * var)).sum(1)) / np.sqrt((var * math.pi * 2).prod(1))
+    return np.log(w * e)
+
+
+def test_log_likes_like_reference_test(khg):
+    # python/tests/test_diag_gmm.py:327-403,528-576
+    rng = np.random.default_rng(20230414)
+    g, w, mean, var = _gmm(khg, rng, 10, 8)
+    x = rng.random(8).astype(np.float32)
+    per = _density(w, mean, var, x)
+    assert abs(g.log_likelihood(x) - np.log(np.exp(per).sum())) < 1e-4
+    assert np.allclose(g.log_likelihoods(x), per, atol=1e-4)
+    X = rng.random((3, 8)).astype(np.float32)
+    got = g.log_likelihoods_matrix(X)
+    assert got.shape == (3, 10)
+    for i in range(3):
+        assert np.allclose(got[i], _density(w, mean, var, X[i]), atol=1e-4)
+    idx = [0, 1, 3, 8, 7, 8, 3, 2]
+    assert np.allclose(g.log_likelihoods_preselect(x, idx), per[idx], atol=1e-4)
+    ll, post = g.component_posteriors(x)
+    sm = np.exp(per - per.max()); sm /= sm.sum()
+    assert np.allclose(post, sm, atol=1e-5) and abs(ll - np.log(np.exp(per).sum())) < 1e-4
+    for i in range(10):
+        assert abs(g.component_log_likelihood(x, i) - per[i]) < 1e-4
+    g2 = khg.DiagGmm(nmix=2, dim=8)
+    with pytest.raises(khg.KhgError):        # "Must call ComputeGconsts() before computing likelihood"
+        g2.log_likelihood(x)
+    with pytest.raises(khg.KhgError):        # dimension mismatch
+        g.log_likelihood(x[:5])
+
+
+def test_accumulate_from_diag_like_reference_test(khg):
+    # python/tests/test_mle_diag_gmm.py:200-252
+    rng = np.random.default_rng(7)
+    g, w, mean, var = _gmm(khg, rng, 10, 8)
+    x = rng.random(8).astype(np.float32)
+    ll0, post = g.component_posteriors(x)
+    for weight in (1.0, 0.25):
+        acc = khg.AccumDiagGmm(g, khg.GmmUpdateFlags.kGmmAll)
+        ll = acc.accumulate_from_diag(gmm=g, data=x, weight=weight)
+        assert abs(ll - ll0) < 1e-5
+        assert np.allclose(acc.occupancy, post * weight, rtol=1e-5)
+        assert np.allclose(acc.mean_accumulator, np.outer(post * weight, x), rtol=1e-5, atol=1e-7)
+        assert np.allclose(acc.variance_accumulator, np.outer(post * weight, x * x), rtol=1e-5, atol=1e-7)
+
+
+def test_invalid_model_raises_like_reference(khg):
+    # decodable-am-diag-gmm.cc:63-65 / diag-gmm.cc:160-162: NaN/Inf log-likelihood -> RuntimeError
+    g = khg.DiagGmm(nmix=2, dim=3)
+    g.set_weights(np.array([0.0, 0.0], np.float32))     # gconsts = -inf for both: log-sum-exp = -inf
+    g.set_means(np.zeros((2, 3), np.float32))
+    assert g.compute_gconsts() == 2
+    with pytest.raises(khg.KhgError):
+        g.log_likelihood(np.zeros(3, np.float32))
+
+
+def _mini_problem(khg, seed=3, n_utt=8):
+    """3-state monophone model over 4 phones, linear transcripts, features drawn from the model."""
+    rng = np.random.default_rng(seed)
+    topo = khg.HmmTopology()
+    s = "<Topology> <TopologyEntry> <ForPhones> 1 2 3 4 </ForPhones> "
+    for i in range(3):
+        s += f"<State> {i} <PdfClass> {i} <Transition> {i} 0.75 <Transition> {i + 1} 0.25 </State> "
+    s += "<State> 3 </State> </TopologyEntry> </Topology>"
+    topo.read(s)
+    D = 6
+    allx = (rng.standard_normal((500, D)) * 3).astype(np.float32)
+    tm, tree, am = khg.gmm_init_mono(topo, allx)
+    # spread the 12 pdfs apart so alignment is well defined
+    true_means = (rng.standard_normal((tm.num_pdfs, D)) * 4).astype(np.float32)
+    for p in range(tm.num_pdfs):
+        g = am.get_pdf(p); g.set_means(true_means[p][None, :]); g.compute_gconsts()
+    utts = []
+    for u in range(n_utt):
+        phones = rng.integers(1, 5, size=int(rng.integers(2, 5)))
+        fst = khg.StdVectorFst()
+        st = fst.add_state(); fst.start = st
+        feats, ali_ref = [], []
+        prev_loop = None
+        for ph in phones:
+            for hs in range(3):
+                pdf = 3 * (ph - 1) + hs
+                loop_tid, fwd_tid = 2 * pdf + 1, 2 * pdf + 2
+                nxt = fst.add_state()
+                fst.add_arc(st, khg.StdArc(fwd_tid, int(ph) if hs == 0 else 0, 0.0, nxt))
+                fst.add_arc(nxt, khg.StdArc(loop_tid, 0, 0.0, nxt))
+                d = int(rng.integers(1, 5))
+                feats.append(true_means[pdf] + rng.standard_normal((d, D)).astype(np.float32))
+                ali_ref += [fwd_tid] + [loop_tid] * (d - 1)
+                st = nxt
+        fst.set_final(st, 0.0)
+        utts.append((f"utt{u}", fst, np.concatenate(feats).astype(np.float32), ali_ref, [int(p) for p in phones]))
+    return topo, tm, tree, am, utts
+
+
+def test_gmm_align_compiled_and_acc_stats_and_est_vs_oracle(khg):
+    """One EM iteration through the reference's four entry points, single-utterance and batched,
+    against the oracle pipeline (AddTransitionProbs -> AlignUtteranceWrapper -> acc-stats -> M-step)."""
+    topo, tm, tree, am, utts = _mini_problem(khg)
+    go, gc, w, miv, iv = am.flat()
+    om = orc.OModel(go, gc, miv, iv)
+    id2pdf = np.asarray(tm.transition_id_to_pdf_array(), np.int32)
+    cfg = khg.AlignConfig(beam=200.0, retry_beam=0.0)
+    num_done = num_err = num_retried = frame_count = 0
+    tot_like = 0.0
+    accs = khg.AccumAmDiagGmm(); accs.init(am, khg.GmmUpdateFlags.kGmmAll)
+    tacc = None
+    oacc = orc.OAccs(int(go[-1]), am.dim, tm.num_transition_ids)
+    alis = []
+    for name, fst, feats, ali_ref, words in utts:
+        f2 = fst.copy()
+        r = khg.gmm_align_compiled(am_gmm=am, transition_model=tm, utt=name, fst=f2, feats=feats, align_config=cfg,
+                                   acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1, num_done=num_done,
+                                   num_error=num_err, num_retried=num_retried, tot_like=tot_like, frame_count=frame_count)
+        num_done, num_err, num_retried, tot_like, frame_count = (r["num_done"], r["num_error"], r["num_retried"], r["tot_like"],
+                                                                  r["frame_count"])
+        c = f2.to_csr()    # f2 now carries the transition probs, like the reference's mutated copy
+        og = orc.OGraph(c["start"], c["arc_off"], c["ilabel"], c["olabel"], c["weight"], c["nextstate"], c["final"])
+        want = orc.align_utterance(og, om, id2pdf, feats, acoustic_scale=0.1)
+        assert want["status"] == 0 and r["alignment"] == want["ali"].tolist() == ali_ref
+        assert r["words"] == want["words"].tolist() == words
+        ll, tacc = khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=feats, ali=r["alignment"],
+                                         transition_accs=tacc)
+        oll = orc.acc_stats_ali(om, id2pdf, feats, want["ali"], oacc)
+        assert ll == pytest.approx(oll, rel=1e-5)
+        alis.append(r["alignment"])
+    assert num_done == len(utts) and num_err == 0 and frame_count == sum(len(u[3]) for u in utts)
+    assert tacc.sum() == frame_count                       # scripts/test_gmm_acc_stats_ali.py:106
+    assert np.array_equal(tacc, oacc.trans_acc)
+    assert accs.tot_count == frame_count and accs.tot_log_like == pytest.approx(oacc.total_log_like, rel=1e-5)
+    # batched variant == loop of single calls
+    rb = khg.gmm_align_compiled_batch(am, tm, [u[0] for u in utts], [u[1] for u in utts], [u[2] for u in utts], cfg,
+                                      acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+    assert rb["alignment"] == alis and rb["num_done"] == num_done and rb["frame_count"] == frame_count
+    assert rb["tot_like"] == pytest.approx(tot_like, rel=1e-6)
+    accs_b = khg.AccumAmDiagGmm(); accs_b.init(am, khg.GmmUpdateFlags.kGmmAll)
+    llb, tacc_b = khg.gmm_acc_stats_ali_batch(am, accs_b, tm, [u[2] for u in utts], alis)
+    assert np.array_equal(tacc_b, tacc)
+    for p in range(am.num_pdfs):
+        np.testing.assert_allclose(accs_b.get_acc(p).occupancy, accs.get_acc(p).occupancy, rtol=1e-12)
+        np.testing.assert_allclose(accs.get_acc(p).mean_accumulator, oacc.mean_acc[go[p]: go[p + 1]], rtol=2e-5, atol=1e-5)
+    # M-step + transition update, then the model must still evaluate (gconsts valid) and have moved
+    before = am.get_pdf(0).means.copy()
+    info = khg.gmm_est(am, accs, tm, tacc, khg.MleTransitionUpdateConfig(), khg.MleDiagGmmOptions(min_gaussian_occupancy=3),
+                       mixup=0, update_flags="mvwt", verbose=False)
+    assert info["gmm_count"] == pytest.approx(frame_count, rel=1e-6) and np.isfinite(info["gmm_objf_impr"])
+    assert not np.allclose(am.get_pdf(0).means, before) or accs.get_acc(0).occupancy.sum() <= 3
+    assert np.isfinite(am.get_pdf(1).log_likelihood(utts[0][2][0]))
+
+
+def _dev(ctx, m, gc, ut, cost, graphs=None):
+    from kaldi_hmm_gmm_amd import DeviceModel, DeviceTransitions, UtteranceSet
+
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    tm.set_trans_cost(cost)
+    us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=graphs if graphs is not None else ut.graphs)
+    return dm, tm, us
+
+
+def test_fallback_kernel_is_exercised_and_exact(ctx):
+    """Long chains (> min_active live states) with a tiny beam defeat the beam certificate, so the
+    order-faithful FasterDecoder kernel decides; it must equal the oracle token for token."""
+    m, gc, om, ut, cost = build(90, 2, 10, n_utt=24, seed=21, min_phones=8, max_phones=20)
+    # weak models (shared means) so that the best path wanders and the beam really prunes
+    dm, tm, us = _dev(ctx, m, gc, ut, cost)
+    poff, pdfs = us.pdf_lists()
+    rng = np.random.default_rng(0)
+    mats = [(-8 * rng.random((poff[u + 1] - poff[u], int(ut.frame_off[u + 1] - ut.frame_off[u])))).astype(np.float32)
+            for u in range(us.n_utt)]
+    us.upload_loglikes(mats)
+    seen_fallback = 0
+    for beam, retry in ((0.8, 4.0), (2.5, 0.0), (200.0, 0.0)):
+        res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=1.0)
+        for u in range(us.n_utt):
+            T = int(ut.frame_off[u + 1] - ut.frame_off[u])
+            want = orc.align_utterance_ll(oracle_graph(ut, u, cost), m.id2pdf, T, pdfs[poff[u]: poff[u + 1]], mats[u],
+                                          acoustic_scale=1.0, beam=beam, retry_beam=retry)
+            st = int(res["status"][u])
+            seen_fallback += (st & 8) != 0
+            assert (st & 3) == (want["status"] & 3), (beam, u, st, want["status"])
+            a = res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]]
+            if want["status"] & 1:
+                assert (a == 0).all()
+            else:
+                assert (a == want["ali"]).all(), (beam, u)
+                assert res["like"][u] == pytest.approx(want["like"], rel=1e-6, abs=1e-4)
+    assert seen_fallback > 0
+
+
+def test_epsilon_arcs_words_careful_and_errors(ctx):
+    """Generic (non register-resident) DP path: epsilon-input arcs with word labels, branches,
+    a graph whose final state is unreachable, an empty graph, a zero-frame utterance."""
+    from kaldi_hmm_gmm_amd import synth
+
+    rng = np.random.default_rng(5)
+    m = synth.make_model(12, 3, 8, seed=5)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    graphs = [random_graph(rng, m.num_tids, n_main=int(rng.integers(3, 9)), p_eps=0.5) for _ in range(10)]
+    graphs.append(random_graph(rng, m.num_tids, n_main=5, with_final=False))        # no final state at all
+    graphs.append({"start": -1, "arc_off": np.zeros(1, np.int64), "ilabel": np.zeros(0, np.int32),
+                   "olabel": np.zeros(0, np.int32), "weight": np.zeros(0, np.float32), "nextstate": np.zeros(0, np.int32),
+                   "final": np.zeros(0, np.float32)})                                 # empty FST
+    T = [int(rng.integers(len(g["final"]) + 1, 30)) for g in graphs]
+    T[3] = 2                                                                          # too short to reach the final
+    frame_off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+    feats = (rng.standard_normal((frame_off[-1], 8)) * 3).astype(np.float32)
+
+    class UT:
+        pass
+    ut = UT(); ut.frame_off = frame_off; ut.feats = feats; ut.graphs = concat(graphs)
+    cost = np.zeros(m.num_tids + 1, np.float32)
+    dm, tm, us = _dev(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    lls = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    for beam, retry in ((200.0, 0.0), (3.0, 9.0)):
+        res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.3)
+        for u, g in enumerate(graphs):
+            og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+            want = orc.align_utterance_ll(og, m.id2pdf, T[u], pdfs[poff[u]: poff[u + 1]], lls[u] if lls[u].size else
+                                          np.zeros((1, max(T[u], 1)), np.float32), acoustic_scale=0.3, beam=beam, retry_beam=retry)
+            st = int(res["status"][u])
+            assert (st & 1) == (want["status"] & 1), (u, st, want["status"])
+            if g["start"] >= 0:
+                assert (st & 2) == (want["status"] & 2), (u, st, want["status"])
+            a = res["ali"][frame_off[u]: frame_off[u + 1]]
+            if want["status"] & 1:
+                assert (a == 0).all()
+            else:
+                assert (a == want["ali"]).all(), (beam, u)
+                w = res["words"][res["words_off"][u]: res["words_off"][u + 1]]
+                assert (w == want["words"]).all()
+                assert res["like"][u] == pytest.approx(want["like"], rel=1e-5, abs=1e-4)
+    assert int(res["status"][10]) & 1 and int(res["status"][11]) & 1
+
+
+def test_exact_ties_follow_reference_token_order(ctx):
+    """Two parallel branches with identical labels and weights tie exactly; the reference keeps the
+    first-inserted token (strict '<', faster-decoder.cc:218-227).  Ties void the DP certificate and the
+    faithful kernel must reproduce the oracle's choice."""
+    from kaldi_hmm_gmm_amd import synth
+
+    m = synth.make_model(6, 2, 5, seed=2)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    # state 0 -(tid 2)-> 1 and 0 -(tid 2)-> 2 (same label, same weight), both -> 3 with tid 4, loops everywhere
+    arcs = [(0, 2, 11, 0.0, 1), (0, 2, 22, 0.0, 2), (1, 1, 0, 0.0, 1), (1, 4, 0, 0.0, 3), (2, 1, 0, 0.0, 2), (2, 4, 0, 0.0, 3),
+            (3, 3, 0, 0.0, 3)]
+    S = 4
+    off = np.zeros(S + 1, np.int64)
+    for a in arcs:
+        off[a[0] + 1] += 1
+    g = {"start": 0, "arc_off": np.cumsum(off), "ilabel": np.array([a[1] for a in arcs], np.int32),
+         "olabel": np.array([a[2] for a in arcs], np.int32), "weight": np.array([a[3] for a in arcs], np.float32),
+         "nextstate": np.array([a[4] for a in arcs], np.int32), "final": np.array([np.inf, np.inf, np.inf, 0.0], np.float32)}
+    rng = np.random.default_rng(1)
+    T = 9
+    feats = (rng.standard_normal((T, 5)) * 2).astype(np.float32)
+
+    class UT:
+        pass
+    ut = UT(); ut.frame_off = np.array([0, T], np.int64); ut.feats = feats; ut.graphs = concat([g])
+    dm, tm, us = _dev(ctx, m, gc, ut, np.zeros(m.num_tids + 1, np.float32))
+    us.loglikes(dm)
+    res = us.align(tm, acoustic_scale=1.0)
+    poff, pdfs = us.pdf_lists()
+    og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+    want = orc.align_utterance_ll(og, m.id2pdf, T, pdfs, us.download_loglikes()[0], acoustic_scale=1.0)
+    assert want["status"] == 0 and int(res["status"][0]) & 8, "a tie must route through the faithful kernel"
+    assert (res["ali"] == want["ali"]).all() and (res["words"] == want["words"]).all()
+
+
+def test_bad_configs_raise(ctx):
+    m, gc, om, ut, cost = build(12, 2, 8, n_utt=2, seed=1)
+    dm, tm, us = _dev(ctx, m, gc, ut, cost)
+    import kaldi_hmm_gmm_amd as khg
+    with pytest.raises(khg.KhgError):          # khg_align before khg_loglikes
+        us.align(tm)
+    us.loglikes(dm)
+    with pytest.raises(khg.KhgError):          # decoder-wrappers.cc:29-33
+        us.align(tm, beam=10.0, retry_beam=5.0)
+    with pytest.raises(khg.KhgError):
+        us.align(tm, beam=0.0)
+    bad = dict(ut.graphs); bad["ilabel"] = bad["ilabel"].copy(); bad["ilabel"][0] = m.num_tids + 5
+    with pytest.raises(khg.KhgError):          # hmm-utils.cc:484-488 invalid symbol on graph input side
+        from kaldi_hmm_gmm_amd import UtteranceSet
+        UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=bad)

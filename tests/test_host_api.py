@@ -1,0 +1,284 @@
+"""CPU-side tests of the host logic behind the reference's names: no GPU needed.
+Golden material comes from the reference's own tests (file:line cited)."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+import kaldi_hmm_gmm_amd as khg
+from kaldi_hmm_gmm_amd import _lib
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TOPO_4PHONES = """
+ <Topology>
+ <TopologyEntry>
+ <ForPhones> 1 </ForPhones>
+ <State> 0 <PdfClass> 0 <Transition> 0 0.5 <Transition> 1 0.5 </State>
+ <State> 1 <PdfClass> 1 <Transition> 1 0.5 <Transition> 2 0.5 </State>
+ <State> 2 <PdfClass> 2 <Transition> 2 0.5 <Transition> 3 0.5 </State>
+ <State> 3 <PdfClass> 3 <Transition> 3 0.5 <Transition> 4 0.5 </State>
+ <State> 4 <PdfClass> 4 <Transition> 4 0.5 <Transition> 5 0.5 </State>
+ <State> 5 </State>
+ </TopologyEntry>
+ <TopologyEntry>
+ <ForPhones> 2 3 4 </ForPhones>
+ <State> 0 <PdfClass> 0 <Transition> 0 0.5 <Transition> 1 0.5 </State>
+ <State> 1 <PdfClass> 1 <Transition> 1 0.5 <Transition> 2 0.5 </State>
+ <State> 2 <PdfClass> 2 <Transition> 2 0.5 <Transition> 3 0.5 </State>
+ <State> 3 </State>
+ </TopologyEntry>
+ </Topology>
+"""
+
+
+def _tm():
+    topo = khg.HmmTopology()
+    topo.read(TOPO_4PHONES)
+    tree = khg.monophone_context_dependency(phones=topo.phones, phone2num_pdf_classes=topo.get_phone_to_num_pdf_classes())
+    return topo, tree, khg.TransitionModel(ctx_dep=tree, hmm_topo=topo)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/khg_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "khg_hip.h")).read()
+    declared = set(re.findall(r"\b(khg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in khg_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.khg_version() == 100
+
+
+def test_no_gpu_fails_loudly():
+    """Without a HIP device the product refuses to run instead of falling back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(khg.KhgError):
+        khg.Context(0)
+
+
+def test_hmm_topology_reference_example():
+    # python/tests/test_hmm_topology.py:13-70
+    s = """<Topology> <TopologyEntry> <ForPhones> 1 3 </ForPhones>
+    <State> 0 <PdfClass> 0 <Transition> 0 0.5 <Transition> 1 0.5 </State>
+    <State> 1 <PdfClass> 1 <Transition> 1 0.5 <Transition> 2 0.5 </State>
+    <State> 2 <PdfClass> 2 <Transition> 2 0.5 <Transition> 3 0.5 </State>
+    <State> 3 </State> </TopologyEntry> </Topology>"""
+    topo = khg.HmmTopology()
+    topo.read(s)
+    assert topo.is_hmm is True
+    assert topo.phones == [1, 3]
+    assert topo.get_phone_to_num_pdf_classes() == [-1, 3, -1, 3]
+    pt = topo.topology_for_phone(1)
+    assert pt[0].forward_pdf_class == 0 and pt[0].self_loop_pdf_class == 0
+    assert pt[0].transitions == [(0, 0.5), (1, 0.5)]
+    assert pt[3].forward_pdf_class == -1 and pt[3].transitions == []
+    assert topo.min_length(1) == 3
+    topo2 = pickle.loads(pickle.dumps(topo, 2))
+    assert str(topo2) == str(topo)
+    with pytest.raises(khg.KhgError):
+        topo.topology_for_phone(2)
+
+
+def test_transition_model_golden():
+    # python/tests/test_transition_model.py:82-142 and the text dump :185-230
+    topo, tree, tm = _tm()
+    assert tm.phones == [1, 2, 3, 4]
+    assert tm.transition_id_to_pdf_array() == [0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10,
+                                               11, 11, 12, 12, 13, 13]
+    assert tm.is_self_loop(1) and not tm.is_self_loop(2) and tm.is_self_loop(3) and not tm.is_self_loop(4)
+    assert tm.transition_ids_equivalent(1, 2) and not tm.transition_ids_equivalent(1, 3)
+    assert tm.transition_ids_is_start_of_phone(1) and tm.transition_ids_is_start_of_phone(2)
+    assert not tm.transition_ids_is_start_of_phone(3)
+    assert [tm.transition_id_to_phone(t) for t in (1, 2, 10, 11, 16, 17)] == [1, 1, 1, 2, 2, 3]
+    assert tm.is_final(1) is False and tm.is_final(10) is True
+    assert tm.num_pdfs == 5 + 3 * 3 and tree.num_pdfs == 14
+    triples = [(t.phone, t.hmm_state, t.forward_pdf) for t in tm.tuples]
+    assert triples == [(1, 0, 0), (1, 1, 1), (1, 2, 2), (1, 3, 3), (1, 4, 4), (2, 0, 5), (2, 1, 6), (2, 2, 7), (3, 0, 8),
+                       (3, 1, 9), (3, 2, 10), (4, 0, 11), (4, 1, 12), (4, 2, 13)]
+    assert "<Triples> 14" in str(tm)
+    lp = np.asarray(tm.log_probs)
+    assert lp[0] == 0 and np.allclose(lp[1:], -0.693147, atol=1e-6) and len(lp) == 29
+    stats = tm.init_stats()
+    assert stats.dtype == np.float64 and stats.shape[0] == tm.num_transition_ids + 1 and stats.sum() == 0
+    stats = tm.accumulate(prob=0.25, trans_id=1, stats=stats)
+    stats = tm.accumulate(prob=0.25, trans_id=1, stats=stats)
+    stats = tm.accumulate(prob=1.0, trans_id=10, stats=stats)
+    assert stats[1] == 0.5 and stats[10] == 1.0
+    tm2 = pickle.loads(pickle.dumps(tm, 2))
+    assert str(tm2.topo) == str(tm.topo) and tm2.state2id == tm.state2id and tm2.id2state == tm.id2state
+    assert tm2.id2pdf_id == tm.id2pdf_id and tm2.log_probs == tm.log_probs and tm2.num_pdfs == tm.num_pdfs
+    assert tm2.non_self_loop_log_probs == tm.non_self_loop_log_probs
+    assert all(str(a) == str(b) for a, b in zip(tm.tuples, tm2.tuples))
+
+
+def test_gmm_update_flags():
+    # python/tests/test_gmm_update_flags.py:9-39
+    assert int(khg.GmmUpdateFlags.kGmmMeans) == 1 and khg.gmm_flags_to_str(khg.GmmUpdateFlags.kGmmMeans) == "m"
+    assert int(khg.GmmUpdateFlags.kGmmVariances) == 2 and int(khg.GmmUpdateFlags.kGmmWeights) == 4
+    assert int(khg.GmmUpdateFlags.kGmmTransitions) == 8
+    assert int(khg.GmmUpdateFlags.kGmmAll) == 15 and khg.gmm_flags_to_str(khg.GmmUpdateFlags.kGmmAll) == "mvwt"
+    assert khg.str_to_gmm_flags("mvwt") == khg.GmmUpdateFlags.kGmmAll == khg.str_to_gmm_flags("a")
+    with pytest.raises(khg.KhgError):
+        khg.str_to_gmm_flags("x")
+    for f in (0, 1, 2, 4, 15):
+        assert khg.augment_gmm_flags(f) == orc.augment_gmm_flags(f)
+
+
+def test_accum_diag_gmm_shapes_and_dtypes():
+    # python/tests/test_mle_diag_gmm.py:48-90
+    g = khg.DiagGmm(nmix=3, dim=4)
+    acc = khg.AccumDiagGmm(g, khg.GmmUpdateFlags.kGmmVariances)
+    assert acc.flags == 7 and acc.occupancy.dtype == np.float64
+    assert acc.mean_accumulator.shape == (3, 4) and acc.variance_accumulator.shape == (3, 4)
+    acc = khg.AccumDiagGmm(g, khg.GmmUpdateFlags.kGmmWeights)
+    assert acc.mean_accumulator.size == 0 and acc.variance_accumulator.size == 0
+    # :92-163 accumulate_for_component / :165-198 accumulate_from_posteriors
+    acc = khg.AccumDiagGmm(g, khg.GmmUpdateFlags.kGmmAll)
+    x = np.arange(4, dtype=np.float32) + 1
+    acc.accumulate_for_component(x, 1, 0.5)
+    assert acc.occupancy[1] == 0.5 and np.allclose(acc.mean_accumulator[1], x * 0.5)
+    assert np.allclose(acc.variance_accumulator[1], x * x * 0.5)
+    post = np.array([0.2, 0.3, 0.5], np.float32)
+    before = (acc.occupancy.copy(), acc.mean_accumulator.copy(), acc.variance_accumulator.copy())
+    acc.accumulate_from_posteriors(x, post)
+    assert np.allclose(acc.occupancy, before[0] + post)
+    assert np.allclose(acc.mean_accumulator, before[1] + np.outer(post, x))
+    assert np.allclose(acc.variance_accumulator, before[2] + np.outer(post, x * x))
+    with pytest.raises(khg.KhgError):
+        acc.set_zero(0x10)
+
+
+def _rand_am(rng, P, G, D):
+    am = khg.AmDiagGmm()
+    for _ in range(P):
+        g = khg.DiagGmm(nmix=G, dim=D)
+        w = rng.random(G).astype(np.float32); w /= w.sum()
+        g.set_weights(w)
+        g.set_invvars((1 / (rng.random((G, D)) + 0.5)).astype(np.float32))
+        g.set_means(rng.standard_normal((G, D)).astype(np.float32))
+        g.compute_gconsts()
+        am.add_pdf(g)
+    return am
+
+
+@pytest.mark.parametrize("flags", ["mvw", "mw", "w", "v"])
+def test_m_step_bit_exact_vs_oracle(flags):
+    """khg_mle_am_diag_gmm_update (product, C++) == oracle restatement of MleDiagGmmUpdate, bit for bit,
+    including low-occupancy removal and variance flooring."""
+    rng = np.random.default_rng(5)
+    P, G, D = 4, 6, 5
+    am = _rand_am(rng, P, G, D)
+    accs = khg.AccumAmDiagGmm()
+    accs.init(am, khg.GmmUpdateFlags.kGmmAll)
+    for p in range(P):
+        a = accs._accs[p]
+        for _ in range(300):
+            x = (rng.standard_normal(D) * 1.2).astype(np.float32)
+            post = rng.random(G).astype(np.float32); post /= post.sum()
+            a.accumulate_from_posteriors(x, post)
+        a.occupancy[1] = 2.0          # -> removed (min_gaussian_occupancy = 10)
+        a.variance_accumulator[2] = a.mean_accumulator[2] ** 2 / a.occupancy[2]   # -> zero variance -> floored
+    ref = []
+    f = int(khg.str_to_gmm_flags(flags))
+    for p in range(P):
+        g, a = am.get_pdf(p), accs._accs[p]
+        ref.append(orc.mle_diag_gmm_update(g.weights, g.means_invvars, g.inv_vars, a.occupancy, a.mean_accumulator,
+                                           a.variance_accumulator, acc_flags=a.flags, flags=f))
+    objf, count = khg.mle_am_diag_gmm_update(khg.MleDiagGmmOptions(), accs, khg.str_to_gmm_flags(flags), am)
+    tot_obj = np.float32(0); tot_cnt = np.float32(0)
+    for p in range(P):
+        g = am.get_pdf(p)
+        assert g.num_gauss == G - 1 == len(ref[p]["weights"])
+        for k, arr in (("weights", g.weights), ("gconsts", g.gconsts), ("means_invvars", g.means_invvars), ("inv_vars", g.inv_vars)):
+            np.testing.assert_array_equal(arr, ref[p][k], err_msg=f"pdf {p} {k}")
+        tot_obj = np.float32(tot_obj + np.float32(ref[p]["obj_change"])); tot_cnt = np.float32(tot_cnt + np.float32(ref[p]["count"]))
+    assert objf == tot_obj and count == tot_cnt
+
+
+def test_transition_mle_update_vs_oracle():
+    topo, tree, tm = _tm()
+    rng = np.random.default_rng(2)
+    stats = tm.init_stats()
+    stats[1:] = rng.integers(0, 50, size=tm.num_transition_ids)
+    stats[3] = 0; stats[4] = 1        # below mincount -> skipped
+    s2i = tm.state2id
+    slo = [0] + [tm.self_loop_of(ts) for ts in range(1, tm.num_transition_states + 1)]
+    lp, nsl, oi, cnt = orc.transition_mle_update(s2i, slo, stats, tm.log_probs, tm.non_self_loop_log_probs)
+    objf, count = tm.mle_update(stats, khg.MleTransitionUpdateConfig())
+    np.testing.assert_array_equal(np.asarray(tm.log_probs, np.float32), lp)
+    np.testing.assert_array_equal(np.asarray(tm.non_self_loop_log_probs, np.float32), nsl)
+    assert objf == oi and count == cnt
+
+
+def test_scaled_trans_cost_vs_oracle_add_transition_probs():
+    topo, tree, tm = _tm()
+    for ts, sl in ((1.0, 1.0), (1.0, 0.1), (0.0, 0.5)):
+        cost = tm.scaled_trans_cost(ts, sl)
+        il = np.arange(tm.num_transition_ids + 1, dtype=np.int32)
+        i2s = np.asarray(tm.id2state, np.int32)
+        w = orc.add_transition_probs(il, np.zeros(il.shape[0], np.float32), tm.log_probs, tm.non_self_loop_log_probs, i2s,
+                                     tm.is_self_loop_array(), ts, sl)
+        np.testing.assert_array_equal(cost[1:], w[1:])
+    fst = khg.StdVectorFst()
+    a, b = fst.add_state(), fst.add_state()
+    fst.start = a
+    fst.add_arc(a, khg.StdArc(2, 0, 0.5, b)); fst.add_arc(b, khg.StdArc(1, 0, 0.0, b)); fst.add_arc(b, khg.StdArc(0, 7, 1.0, b))
+    fst.set_final(b, 0.0)
+    khg.add_transition_probs(trans_model=tm, transition_scale=1.0, self_loop_scale=0.1, fst=fst)
+    c = tm.scaled_trans_cost(1.0, 0.1)
+    assert fst.arcs(a)[0].weight == np.float32(np.float32(0.5) + c[2]) and fst.arcs(b)[0].weight == c[1]
+    assert fst.arcs(b)[1].weight == 1.0
+    fst.add_arc(b, khg.StdArc(999, 0, 0.0, b))
+    with pytest.raises(khg.KhgError):     # csrc/hmm-utils.cc:484-488
+        khg.add_transition_probs(trans_model=tm, transition_scale=1.0, self_loop_scale=1.0, fst=fst)
+
+
+def test_diag_gmm_host_bookkeeping():
+    # python/tests/test_diag_gmm.py:14-106 (set/get), :108-167 (remove_component), pickle :819-848
+    rng = np.random.default_rng(0)
+    nmix, dim = 10, 8
+    g = khg.DiagGmm(nmix=nmix, dim=dim)
+    w = rng.random(nmix).astype(np.float32); w /= w.sum()
+    mean = rng.random((nmix, dim)).astype(np.float32); var = (rng.random((nmix, dim)) + 0.1).astype(np.float32)
+    g.set_weights(w); g.set_means(mean); g.set_invvars(1 / var)
+    assert np.allclose(g.weights, w) and np.allclose(g.means, mean, atol=1e-6) and np.allclose(g.vars, var, rtol=1e-6)
+    assert g.valid_gconsts is False and g.compute_gconsts() == 0 and g.valid_gconsts is True
+    expected = np.log(w) - 0.5 * (dim * np.log(2 * np.pi) + np.log(var).sum(1) + (mean ** 2 / var).sum(1))
+    assert np.allclose(g.gconsts, expected, rtol=1e-5)
+    g.remove_component(3, renorm_weights=True)
+    assert g.num_gauss == 9 and abs(g.weights.sum() - 1) < 1e-6 and g.valid_gconsts is False
+    g.remove_components([0, 5], renorm_weights=False)
+    assert g.num_gauss == 7
+    g.compute_gconsts()
+    g2 = pickle.loads(pickle.dumps(g, 2))
+    assert np.array_equal(g2.weights, g.weights) and np.array_equal(g2.gconsts, g.gconsts) and g2.valid_gconsts
+    am = khg.AmDiagGmm(); am.add_pdf(g); am.add_pdf(g2)
+    am2 = pickle.loads(pickle.dumps(am, 2))
+    assert am2.num_pdfs == 2 and am2.num_gauss == 14 and np.array_equal(am2.get_pdf(1).means_invvars, g.means_invvars)
+    h = []
+    g3 = khg.DiagGmm(gmm=g); g3.split(9, 0.01, history=h, randn=lambda d: np.ones(d, np.float32))
+    assert g3.num_gauss == 9 and len(h) == 2 and abs(g3.weights.sum() - g.weights.sum()) < 1e-6   # :169-237
+
+
+def test_get_split_targets_power_rule():
+    # csrc/model-common.cc:29-70
+    t = khg.get_split_targets(np.array([1000.0, 10.0, 0.0], np.float32), 10, 0.2, 20.0)
+    assert sum(t) <= 10 and t[0] > t[1] >= 1 and t[2] == 1
+    assert khg.get_split_targets(np.array([100.0, 100.0], np.float32), 6, 0.2, 20.0) == [3, 3]
+
+
+def test_shard_utterances_balances_frames():
+    from kaldi_hmm_gmm_amd.dist import shard_utterances
+    T = np.random.default_rng(0).integers(100, 500, size=1000)
+    shards = shard_utterances(T, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(1000))
+    loads = [T[s].sum() for s in shards]
+    assert max(loads) - min(loads) <= T.max()
