@@ -220,7 +220,7 @@ def main():
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
         }
         if not args.no_cpu_baseline and world == 1:
-            ncpu = min(n_local, 256)
+            ncpu = min(n_local, 4096)
             fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)
         else:
