@@ -180,8 +180,9 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
   for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (gauss_off[p + 1] - gauss_off[p] + 31) / 32; }
   m->pdf_tile_off[P] = nt;
   m->ntiles = nt;
-  // tile image: [h][32][ROW] with h=0: means_invvars, h=1: -0.5*inv_vars (exact scaling), then
-  // gconst[32]; padding rows: W = 0, gconst = -inf (contribute exp(-inf) = 0 to the log-sum-exp)
+  // tile image: planes q = 0..3 of [32][ROW]: q=0/1: means_invvars at even/odd d, q=2/3: -0.5*inv_vars
+  // (exact scaling) at even/odd d, element s of a row <-> d = 2s + (q&1); then gconst[32].  Padding
+  // rows: W = 0, gconst = -inf (they contribute exp(-inf) = 0 to the log-sum-exp)
   const int ROW = khg_row_floats(m->KQ), TILE = khg_tile_floats(m->KQ);
   std::vector<float> img((size_t)nt * TILE, 0.0f);
   for (int p = 0; p < P; ++p) {
@@ -192,10 +193,13 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
       if (g < G) {
         const float* mi = miv + (size_t)(gauss_off[p] + g) * D;
         const float* v = iv + (size_t)(gauss_off[p] + g) * D;
-        for (int d = 0; d < D; ++d) { t[(0 * 32 + r) * ROW + d] = mi[d]; t[(1 * 32 + r) * ROW + d] = -0.5f * v[d]; }
-        t[2 * 32 * ROW + r] = gconsts[gauss_off[p] + g];
+        for (int d = 0; d < D; ++d) {
+          t[((d & 1) * 32 + r) * ROW + (d >> 1)] = mi[d];
+          t[((2 + (d & 1)) * 32 + r) * ROW + (d >> 1)] = -0.5f * v[d];
+        }
+        t[4 * 32 * ROW + r] = gconsts[gauss_off[p] + g];
       } else {
-        t[2 * 32 * ROW + r] = -INFINITY;
+        t[4 * 32 * ROW + r] = -INFINITY;
       }
     }
   }
@@ -477,7 +481,7 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
   if (aligned) hipLaunchKernelGGL((k1_loglikes<KQ, NF, true, WPS>), dim3(nchunks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
 }
-static constexpr int k1_nf(int KQ) { return KQ == 10 ? 3 : 4; }
+static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); int v = e ? atoi(e) : 6; return (v >= 3 && v <= 6) ? v : 6; }   // 16-frame tiles per wave
 
 extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
@@ -493,25 +497,25 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
     if (!rc) rc = dev_alloc(&u->ll_d, (size_t)u->ll_total);
     if (rc) return rc;
   }
-  if (!u->chunks_d || u->chunk_kq != m->KQ) {
+  if (!u->chunks_d || u->chunk_kq != m->KQ * 16 + k1_nf(m->KQ)) {
     DEVFREE(u->chunks_d);
     const int maxtiles = 4 * k1_nf(m->KQ);
     std::vector<K1Chunk> ch;
     for (int i = 0; i < u->n_utt; ++i) {
       int64_t T = u->frame_off[i + 1] - u->frame_off[i];
       if (T <= 0 || u->pdf_off[i + 1] == u->pdf_off[i]) continue;
-      int n32 = (int)((T + 31) / 32);
-      int nchunks = (n32 + maxtiles - 1) / maxtiles;
-      int per = (n32 + nchunks - 1) / nchunks;
+      int n16 = (int)((T + 15) / 16);
+      int nchunks = (n16 + maxtiles - 1) / maxtiles;
+      int per = (n16 + nchunks - 1) / nchunks;
       for (int c = 0; c < nchunks; ++c) {
-        int t0 = c * per * 32;
-        int nfr = (int)std::min<int64_t>((int64_t)per * 32, T - t0);
+        int t0 = c * per * 16;
+        int nfr = (int)std::min<int64_t>((int64_t)per * 16, T - t0);
         if (nfr <= 0) break;
         ch.push_back(K1Chunk{i, t0, nfr, 0});
       }
     }
     u->n_chunks = (int)ch.size();
-    u->chunk_kq = m->KQ;
+    u->chunk_kq = m->KQ * 16 + k1_nf(m->KQ);
     rc = dev_upload(ctx, &u->chunks_d, ch);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
@@ -523,8 +527,13 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
-    if (m->KQ == 10) launch_k1<10, 3, 2>(a, u->n_chunks, aligned, ctx->stream);
-    else launch_k1<20, 4, 1>(a, u->n_chunks, aligned, ctx->stream);
+    const int nf = k1_nf(m->KQ);
+    if (m->KQ == 10) {
+      if (nf == 3) launch_k1<10, 3, 4>(a, u->n_chunks, aligned, ctx->stream);
+      else if (nf == 4) launch_k1<10, 4, 3>(a, u->n_chunks, aligned, ctx->stream);
+      else if (nf == 5) launch_k1<10, 5, 2>(a, u->n_chunks, aligned, ctx->stream);
+      else launch_k1<10, 6, 2>(a, u->n_chunks, aligned, ctx->stream);
+    } else launch_k1<20, 6, 1>(a, u->n_chunks, aligned, ctx->stream);
     HIPCHK(hipGetLastError());
   }
   u->ll_valid = true;

@@ -66,12 +66,16 @@ void orc_loglikes(int32_t G, int32_t D, const float *gconsts, const float *means
 void orc_loglikes_fma_order(int32_t G, int32_t D, const float *gconsts,
                             const float *means_invvars, const float *inv_vars, const float *x,
                             float *out) {
+  /* K1's MFMA step s consumes (M[2s]x[2s], M[2s+1]x[2s+1], V'[2s]x2[2s], V'[2s+1]x2[2s+1]), V' = -0.5 V */
   for (int32_t g = 0; g < G; ++g) {
     const float *mi = means_invvars + (size_t)g * D, *iv = inv_vars + (size_t)g * D;
     float s = gconsts[g];
-    for (int32_t d = 0; d < D; ++d) {
+    for (int32_t d = 0; d < D; d += 2) {
+      int has2 = d + 1 < D;
       s = fmaf(mi[d], x[d], s);
+      if (has2) s = fmaf(mi[d + 1], x[d + 1], s);
       s = fmaf(-0.5f * iv[d], x[d] * x[d], s);
+      if (has2) s = fmaf(-0.5f * iv[d + 1], x[d + 1] * x[d + 1], s);
     }
     out[g] = s;
   }

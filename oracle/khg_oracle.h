@@ -63,7 +63,7 @@ void orc_loglikes(int32_t G, int32_t D, const float *gconsts, const float *means
                   const float *inv_vars, const float *x, float *out);
 
 /* Same expression evaluated in the order the HIP MFMA kernel uses:
- * s = gconst; for d: s = fmaf(miv[d], x[d], s); s = fmaf(-0.5f*iv[d], x[d]*x[d], s).
+ * s = gconst; for d in steps of 2: fmaf(miv[d]x[d]), fmaf(miv[d+1]x[d+1]), fmaf(-0.5iv[d]x[d]^2), fmaf(-0.5iv[d+1]x[d+1]^2).
  * Not a reference function: lets tests separate "contraction order" from "kernel bug". */
 void orc_loglikes_fma_order(int32_t G, int32_t D, const float *gconsts, const float *means_invvars,
                             const float *inv_vars, const float *x, float *out);
