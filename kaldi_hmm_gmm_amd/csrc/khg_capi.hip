@@ -801,13 +801,23 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     }
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
-    const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + (maxG | 1) + 4);
-    if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
-    const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : (const void*)k3_accumulate<20>;
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
-    const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
-    {
+    const bool use_mfma = maxG <= 128 && getenv("KHG_K3_VALU") == nullptr;
+    if (use_mfma) {
+      // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
+      const size_t lds = sizeof(float) * ((size_t)K3_CHUNK * 4 * m->KQ + 5 * K3_CHUNK);
+      const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(32, (avg_chunks + 7) / 8));
+      KernelTimer kt(ctx, "k3_accumulate");
+      if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+      else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+      else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+      else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+    } else {
+      const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + (maxG | 1) + 4);
+      if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
+      const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : (const void*)k3_accumulate<20>;
+      if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
       KernelTimer kt(ctx, "k3_accumulate");
       if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
       else hipLaunchKernelGGL(k3_accumulate<20>, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
