@@ -283,6 +283,8 @@ struct khg_utts {
   float *in_w_d = nullptr, *final_d = nullptr;
   // K1
   K1Chunk* chunks_d = nullptr; int32_t n_chunks = 0; int32_t chunk_kq = 0;
+  int64_t* tile_off_d = nullptr; int32_t* tiles_d = nullptr;
+  std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
   float* ll_d = nullptr; int64_t ll_total = 0; bool ll_valid = false;
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
@@ -437,6 +439,7 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   for (int i = 0; i < u->n_utt; ++i) { u->pdf_off[i + 1] = u->pdf_off[i] + n; u->pdfs.insert(u->pdfs.end(), pdfs, pdfs + n); }
   plan_ll(u);
   DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d);
+  DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear();
   u->ll_valid = false;
   return KHG_OK;
 }
@@ -447,7 +450,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->frame_off_d); DEVFREE(u->state_off_d); DEVFREE(u->pdf_off_d); DEVFREE(u->ll_off_d);
   DEVFREE(u->pdfs_d); DEVFREE(u->start_d); DEVFREE(u->in_off_d); DEVFREE(u->out_off_d);
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
-  DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d);
+  DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
@@ -481,7 +484,7 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
   if (aligned) hipLaunchKernelGGL((k1_loglikes<KQ, NF, true, WPS>), dim3(nchunks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
 }
-static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); int v = e ? atoi(e) : 6; return (v >= 3 && v <= 6) ? v : 6; }   // 16-frame tiles per wave
+static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); int v = e ? atoi(e) : 5; return (v >= 3 && v <= 6) ? v : 5; }   // 16-frame tiles per wave
 
 extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
@@ -520,9 +523,30 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
   }
+  if (u->tiles_pto != m->pdf_tile_off) {
+    // per-utterance W-tile walk for this model's tile layout (it only changes when the number of
+    // Gaussians of some pdf crosses a multiple of 32): for every pdf on the utterance's list its
+    // tiles in order, bit 31 marking the last tile of a pdf
+    DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
+    std::vector<int64_t> toff((size_t)u->n_utt + 1, 0);
+    std::vector<int32_t> tiles;
+    for (int i = 0; i < u->n_utt; ++i) {
+      for (int64_t k = u->pdf_off[i]; k < u->pdf_off[i + 1]; ++k) {
+        const int p = u->pdfs[(size_t)k];
+        for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t)
+          tiles.push_back(t | (t + 1 == m->pdf_tile_off[p + 1] ? (int32_t)0x80000000 : 0));
+      }
+      toff[(size_t)i + 1] = (int64_t)tiles.size();
+    }
+    rc = dev_upload(ctx, &u->tile_off_d, toff);
+    if (!rc) rc = dev_upload(ctx, &u->tiles_d, tiles);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u->tiles_pto = m->pdf_tile_off;
+  }
   K1Args a;
   a.feats = u->feats_d; a.frame_off = u->frame_off_d; a.chunks = u->chunks_d; a.wimg = m->wimg_d;
-  a.pdf_tile_off = m->pdf_tile_off_d; a.utt_pdf_off = u->pdf_off_d; a.utt_pdfs = u->pdfs_d;
+  a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d; a.D = m->D;
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
@@ -533,7 +557,7 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
       else if (nf == 4) launch_k1<10, 4, 3>(a, u->n_chunks, aligned, ctx->stream);
       else if (nf == 5) launch_k1<10, 5, 2>(a, u->n_chunks, aligned, ctx->stream);
       else launch_k1<10, 6, 2>(a, u->n_chunks, aligned, ctx->stream);
-    } else launch_k1<20, 6, 1>(a, u->n_chunks, aligned, ctx->stream);
+    } else launch_k1<20, 5, 1>(a, u->n_chunks, aligned, ctx->stream);
     HIPCHK(hipGetLastError());
   }
   u->ll_valid = true;

@@ -53,6 +53,34 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
+@pytest.mark.parametrize("G,D", [(64, 40), (20, 13), (40, 80)])
+def test_loglikes_long_utterances(ctx, G, D):
+    """Utterance lengths that give a wave 0..NF frame tiles, uneven remainders, partial last tiles
+    and more than one chunk per utterance (features-only set, one shared pdf list)."""
+    from kaldi_hmm_gmm_amd import DeviceModel, UtteranceSet
+
+    P = 90 if G == 64 else 12       # 75 pdfs x 2 W tiles: a walk list longer than two 64-entry blocks
+    m, gc, om, ut, cost = build(P, G, D, n_utt=2, seed=G + D, ragged=(G == 20))
+    lens = np.array([1, 15, 16, 17, 63, 64, 65, 97, 160, 161, 255, 300, 320, 333, 384, 400, 480, 481, 700, 1111])
+    frame_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rng = np.random.default_rng(G * 100 + D)
+    feats = (rng.standard_normal((int(frame_off[-1]), D)) * 1.5 + 0.3).astype(np.float32)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    us = UtteranceSet(ctx, None, frame_off, feats)
+    pl = np.sort(rng.choice(P, 75, replace=False)).astype(np.int32) if P == 90 else np.array([0, 3, 4, 7, 11], np.int32)
+    us.set_pdf_list(pl)
+    us.loglikes(dm)
+    got = us.download_loglikes()
+    for u in range(len(lens)):
+        x = feats[frame_off[u]: frame_off[u + 1]]
+        exact, bound = exact_loglikes(m, gc, x, pl)
+        tol = LL_ATOL + LL_RTOL * bound
+        assert got[u].shape == exact.shape
+        assert np.isfinite(got[u]).all(), f"utt {u} (T={lens[u]}): non-finite log-likes"
+        err = np.abs(got[u] - exact)
+        assert (err <= tol).all(), f"utt {u} (T={lens[u]}): max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    us.close()
+
 
 def test_loglikes_fma_order_bitwise_gemm(ctx):
     """The MFMA contraction is bit-for-bit the k-ordered fmaf chain the oracle restates; only

@@ -17,7 +17,8 @@ for T in [int(a) for a in sys.argv[1:]] or [300, 384, 320, 256, 288]:
     feats = rng.standard_normal((U * T, D)).astype(np.float32)
     us = UtteranceSet(ctx, None, frame_off, feats)
     # per-utterance random pdf lists are not supported for features-only sets: use one random list of 75
-    us.set_pdf_list(np.sort(rng.choice(P, 75, replace=False)).astype(np.int32))
+    import os
+    us.set_pdf_list(np.full(75, 7, np.int32) if os.environ.get('SAMEPDF') else np.sort(rng.choice(P, 75, replace=False)).astype(np.int32))
     us.loglikes(dm); ctx.sync()
     ctx.set_timing(True)
     for _ in range(3): us.loglikes(dm)
