@@ -402,7 +402,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
           out_inidx[a] = (int32_t)(pos - a0);
         }
       }
-      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 256);  // >= 256 B per layer: room for the packed fast-path format
+      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 384);  // >= 384 B per layer: room for the packed fast-path format (3 bits per state, whole waves)
       u->path_off[i + 1] = u->path_off[i] + T + S + 8;
       u->words_off[i + 1] = u->words_off[i] + nwords;
     }
@@ -660,9 +660,10 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const bool fast = !u->has_eps && u->max_indeg <= 3 && S <= 4096;   // whole batch takes the register-resident path
   const int KSsel = !fast ? 0 : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4));
   const size_t NSl = fast ? KSsel : 1;
-  const size_t LBmax = fast ? 16 * nwave * NSl : ((S + 15) & ~size_t(15));
+  const size_t PERmax = (nwave * NSl * 3 + 1) & ~size_t(1);   // u64 words per layer of packed back-pointers (see k2_viterbi_dp)
+  const size_t LBmax = fast ? 8 * PERmax : ((S + 15) & ~size_t(15));
   // cur | nxt | packed bp block (fast) | reductions | arcs | in_off | wave minima/counts | flags | [align] | max(score block (generic), trace-back block)
-  size_t lds_dp = 16 * S + (fast ? 8 * K2_FB * nwave * NSl * 2 : 0) + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
+  size_t lds_dp = 16 * S + (fast ? 8 * K2_FB * PERmax : 0) + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
                   std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), (K2_FB + 1) * LBmax) + 64;
   size_t HB = std::max<size_t>(2 * S, 1000);
   size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
