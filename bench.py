@@ -38,6 +38,21 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(frames_per_launch):
+    """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), valid only for
+    the launch size it was collected at -- bench.py cannot run the profiler on itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as fh:
+            pm = json.load(fh)
+        k1 = next(v for k, v in pm["kernels"].items() if k.startswith("k1_loglikes"))
+        if abs(pm["frames_per_launch"] / frames_per_launch - 1.0) > 0.02:
+            return None, None
+        return k1["traffic_bytes"], "profiles/r1_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same launch size)"
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     """The oracle (CPU restatement, kind="port") timed on a bounded sample of the SAME workload:
     AlignUtteranceWrapper + acc-stats per utterance, one thread -- the reference's execution model."""
@@ -194,6 +209,7 @@ def main():
 
     if rank == 0:
         res = accs.download()
+        traffic, traffic_src = pmc_traffic(frames_local / nb)
         out = {
             "metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss",
             "value": frames_total * args.steps / dt,
@@ -214,7 +230,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k1_loglikes", "achieved": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
+                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
             "check": {"acc_total_frames": res["total_frames"] , "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},

@@ -1,0 +1,135 @@
+"""Turn the rocprofv3 output of tools/profile_r1.sh (gpurun_out/prof_r1/) into the committed summaries:
+
+  profiles/r1_kernel_stats.csv      kernel-trace --stats rows (our kernels first)
+  profiles/r1_pmc_summary.json      per-kernel per-launch PMC averages (+ the gfx950 corrections)
+  profiles/r1_bench_under_rocprof.json   the bench line printed under the profiler
+  profiles/README.md                tables of the above
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md "HBM [CDNA4]": FETCH_SIZE and WRITE_SIZE come
+from separate --pmc passes, are reported in KB, and on gfx950 FETCH_SIZE counts wide (16 B/lane)
+streaming reads at exactly half their bytes -> doubled here; WRITE_SIZE is taken as is.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r1"
+OURS = ("k1_loglikes", "k2_viterbi", "k3_")
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "") if any(o in name for o in OURS) else name[:60]
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    if not f:
+        raise SystemExit(f"missing {pattern} under {SRC}")
+    return f[0]
+
+
+def counters(sub):
+    """-> {kernel: {counter: [values per dispatch]}}"""
+    out = {}
+    with open(one(f"{sub}/*/*_counter_collection.csv")) as fh:
+        for r in csv.DictReader(fh):
+            k = r["Kernel_Name"]
+            if not any(o in k for o in OURS):
+                continue
+            out.setdefault(short(k), {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            out[short(k)][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: {c: list(v.values()) for c, v in d.items()} for k, d in out.items()}
+
+
+def mean(v):
+    return sum(v) / len(v) if v else 0.0
+
+
+stats = []
+with open(one("trace/*/*_kernel_stats.csv")) as fh:
+    for r in csv.DictReader(fh):
+        stats.append(r)
+stats.sort(key=lambda r: (0 if any(o in r["Name"] for o in OURS) else 1, -float(r["TotalDurationNs"])))
+with open(os.path.join(DST, f"{TAG}_kernel_stats.csv"), "w", newline="") as fh:
+    w = csv.DictWriter(fh, fieldnames=list(stats[0].keys()))
+    w.writeheader()
+    for r in stats[:16]:
+        w.writerow(r)
+
+bench_line = None
+with open(os.path.join(SRC, "bench_trace.json")) as fh:
+    for line in fh:
+        if line.startswith("{"):
+            bench_line = json.loads(line)
+if bench_line:
+    with open(os.path.join(DST, f"{TAG}_bench_under_rocprof.json"), "w") as fh:
+        json.dump(bench_line, fh, indent=1)
+
+fetch = counters("pmc_fetch")
+write = counters("pmc_write")
+mfma = counters("pmc_mfma")
+summary = {"command": "tools/profile_r1.sh", "kernels": {}}
+if bench_line:
+    nb = bench_line["roofline"]["launches_per_step"]
+    summary["utterances_per_launch"] = bench_line["config"]["utterances"] / nb
+    summary["frames_per_launch"] = bench_line["config"]["frames_per_step"] / nb
+for k in sorted(set(fetch) | set(write) | set(mfma)):
+    e = {}
+    if k in fetch:
+        kb = mean(fetch[k].get("FETCH_SIZE", []))
+        e["FETCH_SIZE_KB"] = kb
+        e["read_bytes_corrected"] = kb * 1024.0 * 2.0          # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+    if k in write:
+        kb = mean(write[k].get("WRITE_SIZE", []))
+        e["WRITE_SIZE_KB"] = kb
+        e["write_bytes"] = kb * 1024.0
+    if "read_bytes_corrected" in e and "write_bytes" in e:
+        e["traffic_bytes"] = e["read_bytes_corrected"] + e["write_bytes"]
+    if k in mfma:
+        busy = mean(mfma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", []))
+        gui = mean(mfma[k].get("GRBM_GUI_ACTIVE", []))
+        e["SQ_VALU_MFMA_BUSY_CYCLES"] = busy
+        e["GRBM_GUI_ACTIVE"] = gui
+        e["SQ_INSTS_VALU_MFMA_MOPS_F32"] = mean(mfma[k].get("SQ_INSTS_VALU_MFMA_MOPS_F32", []))
+        # busy cycles are summed over the 1024 SIMDs, GUI_ACTIVE over the 8 XCDs
+        e["mfma_busy_frac"] = (busy / 1024.0) / (gui / 8.0) if gui else None
+    for r in stats:
+        if short(r["Name"]) == k:
+            e["calls"] = int(r["Calls"])
+            e["avg_ms"] = float(r["AverageNs"]) / 1e6
+    summary["kernels"][k] = e
+with open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w") as fh:
+    json.dump(summary, fh, indent=1)
+
+lines = [f"# Round {TAG[1:]} rocprofv3 summaries (MI355X, gfx950)", "",
+         "Produced by `tools/profile_r1.sh` on the GPU box and `tools/summarize_prof.py` here: one",
+         "`rocprofv3 --kernel-trace --stats` run of `python3 bench.py --utts 25000 --steps 2 --warmup 1 --batches 2",
+         "--no-cpu-baseline` (12 500 utterances per launch, the same launch size as the default 100 000-utterance",
+         "bench with 8 batches), then three separate `--pmc` runs of the same command (FETCH_SIZE | WRITE_SIZE |",
+         "SQ_* + GRBM_GUI_ACTIVE).", "",
+         f"## Kernel trace ({TAG}_kernel_stats.csv)", "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
+for r in stats[:10]:
+    lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {r['Percentage']} |")
+lines += ["", f"## PMC, per launch ({TAG}_pmc_summary.json)", "",
+          "| kernel | FETCH_SIZE KB | reads, corrected x2 (GB) | WRITE_SIZE (GB) | traffic (GB) | MFMA busy frac |", "|---|---|---|---|---|---|"]
+for k, e in summary["kernels"].items():
+    if "FETCH_SIZE_KB" not in e:
+        continue
+    mb = e.get("mfma_busy_frac")
+    lines.append(f"| `{k}` | {e['FETCH_SIZE_KB']:.0f} | {e['read_bytes_corrected'] / 1e9:.2f} | {e.get('write_bytes', 0) / 1e9:.2f} | "
+                 f"{e.get('traffic_bytes', 0) / 1e9:.2f} | {'' if mb is None else f'{mb:.3f}'} |")
+if bench_line:
+    rf = bench_line["roofline"]
+    lines += ["", f"Bench line under the profiler ({TAG}_bench_under_rocprof.json): K1 {rf['kernel_ms']:.2f} ms per launch by HIP events, "
+              f"{rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of the 157.3 TFLOP/s fp32 MFMA peak."]
+notes = os.path.join(DST, f"{TAG}_notes.md")
+if os.path.exists(notes):
+    lines += ["", open(notes).read().rstrip()]
+with open(os.path.join(DST, "README.md"), "w") as fh:
+    fh.write("\n".join(lines) + "\n")
+print("\n".join(lines))
