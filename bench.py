@@ -58,27 +58,63 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     AlignUtteranceWrapper + acc-stats per utterance, one thread -- the reference's execution model."""
     from oracle import oracle as orc
 
+    import concurrent.futures as cf
+
     om = orc.OModel(model.gauss_off, gc, model.means_invvars, model.inv_vars)
-    oa = orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids)
     g = dict(ut.graphs)
     g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[g["ilabel"]], g["weight"]).astype(np.float32)
-    frames = 0
-    n = 0
-    t0 = time.perf_counter()
-    for u in range(feats_host["n"]):
+    nmax = feats_host["n"]
+
+    def one(u, oa):
         og = orc.OGraph.from_set(g, u)
         f = feats_host["feats"][ut.frame_off[u]: ut.frame_off[u + 1]]
         r = orc.align_utterance(og, om, model.id2pdf, f, acoustic_scale=0.1)
         if (r["status"] & 1) == 0:
             orc.acc_stats_ali(om, model.id2pdf, f, r["ali"], oa)
-        frames += f.shape[0]
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 4:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} utterances ({frames} frames) of rank 0's shard, oracle/khg_oracle.c "
-                      f"(gcc -O2, 1 thread): FasterDecoder+GMM decodable+acc-stats, {dt:.1f}s"}
+        return f.shape[0]
+
+    # (A) one thread: the reference's execution model (its scripts loop over utterances in Python)
+    oa = orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids)
+    frames1 = n1 = 0
+    t0 = time.perf_counter()
+    while n1 < nmax and (time.perf_counter() - t0 < budget_s / 2 or n1 < 4):
+        frames1 += one(n1, oa)
+        n1 += 1
+    dt1 = time.perf_counter() - t0
+    # (B) utterance-parallel over the host cores (ctypes releases the GIL inside the C oracle), one
+    # private accumulator set per thread -- the fairest CPU figure the same code can give
+    nthr = max(1, min(os.cpu_count() or 1, 32))
+    accs = [orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids) for _ in range(nthr)]
+    nxt = [n1]
+    import threading
+    lock = threading.Lock()
+    done = [0, 0]
+    tb = time.perf_counter()
+
+    def worker(k):
+        fr = nn = 0
+        while time.perf_counter() - tb < budget_s / 2:
+            with lock:
+                u = nxt[0]
+                nxt[0] += 1
+            if u >= nmax:
+                break
+            fr += one(u, accs[k])
+            nn += 1
+        return fr, nn
+
+    with cf.ThreadPoolExecutor(nthr) as ex:
+        for fr, nn in ex.map(worker, range(nthr)):
+            done[0] += fr
+            done[1] += nn
+    dtb = time.perf_counter() - tb
+    par = done[0] / dtb if done[1] else 0.0
+    one_thr = frames1 / dt1
+    best, cores = (par, nthr) if par > one_thr else (one_thr, 1)
+    return {"value": best, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread_value": one_thr,
+            "sample": f"oracle/khg_oracle.c (gcc -O2): FasterDecoder + GMM decodable + acc-stats per utterance of rank 0's shard; "
+                      f"1 thread: first {n1} utterances ({frames1} frames) in {dt1:.1f}s; {nthr} threads (utterance-parallel, "
+                      f"private accumulators): next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
 
 
 def main():
@@ -237,7 +273,7 @@ def main():
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
         }
         if not args.no_cpu_baseline and world == 1:
-            ncpu = min(n_local, 4096)
+            ncpu = min(n_local, 16384)
             fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)
         else:
