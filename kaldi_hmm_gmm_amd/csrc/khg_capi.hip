@@ -484,7 +484,8 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
   if (aligned) hipLaunchKernelGGL((k1_loglikes<KQ, NF, true, WPS>), dim3(nchunks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
 }
-static int k1_nf(int /*KQ*/) { return 5; }   // 16-frame tiles per wave (register budget: 5 x 20 B-operand VGPRs at 2 waves/SIMD)
+// 16-frame tiles per wave: 6 x 20 B-operand VGPRs fit 2 waves/SIMD at D <= 40 (KHG_K1_NF=5 selects the smaller chunk)
+static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); return KQ != 10 ? 5 : (e && atoi(e) == 5) ? 5 : 6; }
 
 extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
@@ -551,7 +552,8 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
-    if (m->KQ == 10) launch_k1<10, 5, 2>(a, u->n_chunks, aligned, ctx->stream);
+    if (m->KQ == 10 && k1_nf(10) == 6) launch_k1<10, 6, 2>(a, u->n_chunks, aligned, ctx->stream);
+    else if (m->KQ == 10) launch_k1<10, 5, 2>(a, u->n_chunks, aligned, ctx->stream);
     else launch_k1<20, 5, 1>(a, u->n_chunks, aligned, ctx->stream);
     HIPCHK(hipGetLastError());
   }
