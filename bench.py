@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--retry-beam", type=float, default=0.0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batches", type=int, default=8, help="utterance batches per rank")
+    ap.add_argument("--batches", type=int, default=1, help="utterance batches per rank (more batches bound the score/back-pointer buffers and let a batch's serial fallback decoder overlap the next batch's K1)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--seed", type=int, default=20230418)
     return ap.parse_args()

@@ -108,10 +108,9 @@ with open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w") as fh:
 
 lines = [f"# Round {TAG[1:]} rocprofv3 summaries (MI355X, gfx950)", "",
          "Produced by `tools/profile_r1.sh` on the GPU box and `tools/summarize_prof.py` here: one",
-         "`rocprofv3 --kernel-trace --stats` run of `python3 bench.py --utts 25000 --steps 2 --warmup 1 --batches 2",
-         "--no-cpu-baseline` (12 500 utterances per launch, the same launch size as the default 100 000-utterance",
-         "bench with 8 batches), then three separate `--pmc` runs of the same command (FETCH_SIZE | WRITE_SIZE |",
-         "SQ_* + GRBM_GUI_ACTIVE).", "",
+         "`rocprofv3 --kernel-trace --stats` run of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
+         "(the default workload: 100 000 utterances, one launch of each kernel per step), then three separate",
+         "`--pmc` runs of the same command (FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE).", "",
          f"## Kernel trace ({TAG}_kernel_stats.csv)", "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
 for r in stats[:10]:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {r['Percentage']} |")
