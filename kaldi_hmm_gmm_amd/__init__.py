@@ -18,4 +18,5 @@ from .mle import (AccumAmDiagGmm, AccumDiagGmm, GmmUpdateFlags, MleDiagGmmOption
                   str_to_gmm_flags)
 from .scripts import (gmm_acc_stats_ali, gmm_acc_stats_ali_batch, gmm_align_compiled, gmm_align_compiled_batch,  # noqa: F401
                       gmm_boost_silence, gmm_est, gmm_init_mono)
+from .training_graph import TrainingGraphCompiler, TrainingGraphCompilerOptions, equal_align, generate_hmm_topo  # noqa: F401
 from .transition_model import MleTransitionUpdateConfig, TransitionModel, TransitionModelTuple, get_pdfs_for_phones  # noqa: F401

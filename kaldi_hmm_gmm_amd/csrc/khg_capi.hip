@@ -402,7 +402,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
           out_inidx[a] = (int32_t)(pos - a0);
         }
       }
-      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 384);  // >= 384 B per layer: room for the packed fast-path format (3 bits per state, whole waves)
+      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 512);  // >= 512 B per layer: room for the packed fast-path format (<= 4 bits per state, whole waves)
       u->path_off[i + 1] = u->path_off[i] + T + S + 8;
       u->words_off[i + 1] = u->words_off[i] + nwords;
     }
@@ -654,10 +654,12 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   // threads: one destination state each (up to 1024), KS states per thread beyond that
   const int nthr = (int)std::min<size_t>(1024, (S + 63) / 64 * 64);
   const size_t nwave = nthr / 64;
-  const bool fast = !u->has_eps && u->max_indeg <= 3 && S <= 4096;   // whole batch takes the register-resident path
+  // register-resident path for the whole batch: in-degree <= 3 (up to 4 states per thread) or <= 6 (one state per thread)
+  const bool deg6 = !u->has_eps && u->max_indeg > 3 && u->max_indeg <= 6 && S <= 1024;
+  const bool fast = deg6 || (!u->has_eps && u->max_indeg <= 3 && S <= 4096);
   const int KSsel = !fast ? 0 : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4));
   const size_t NSl = fast ? KSsel : 1;
-  const size_t PERmax = (nwave * NSl * 3 + 1) & ~size_t(1);   // u64 words per layer of packed back-pointers (see k2_viterbi_dp)
+  const size_t PERmax = (nwave * NSl * (deg6 ? 4 : 3) + 1) & ~size_t(1);   // u64 words per layer of packed back-pointers (see k2_viterbi_dp)
   const size_t LBmax = fast ? 8 * PERmax : ((S + 15) & ~size_t(15));
   // cur | nxt | packed bp block (fast) | reductions | arcs | in_off | wave minima/counts | flags | [align] | max(score block (generic), trace-back block)
   size_t lds_dp = 16 * S + (fast ? 8 * K2_FB * PERmax : 0) + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
@@ -667,13 +669,14 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   if (lds_dp > 160 * 1024 || lds_f > 160 * 1024)
     return khg_set_error(KHG_E_UNSUPPORTED, "khg_align: decoding graph too large for the LDS-resident Viterbi kernels (" +
                                                 std::to_string(u->max_states) + " states, " + std::to_string(u->max_inarcs) + " arcs)");
-  const void* k2fn = KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
+  const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
                    : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
   if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
   if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
   {
     KernelTimer kt(ctx, "k2_viterbi_dp");
-    if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 2) hipLaunchKernelGGL((k2_viterbi_dp<2, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 4) hipLaunchKernelGGL((k2_viterbi_dp<4, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);

@@ -241,6 +241,35 @@ class TransitionModel:
     def get_transition_log_prob(self, trans_id):
         return float(self._log_probs[trans_id])
 
+    def tuple_to_transition_state(self, phone: int, hmm_state: int, pdf: int, self_loop_pdf: int) -> int:
+        """csrc/transition-model.cc:432-447 (1-based; throws when the tuple is absent)."""
+        import bisect
+        t = TransitionModelTuple(phone, hmm_state, pdf, self_loop_pdf)
+        i = bisect.bisect_left(self._tuples, t)
+        if i == len(self._tuples) or not (self._tuples[i] == t):
+            raise KhgError("TransitionModel::TupleToTransitionState, tuple not found. (incompatible tree and model?)")
+        return i + 1
+
+    def pair_to_transition_id(self, trans_state: int, trans_index: int) -> int:
+        """csrc/transition-model.cc:385-390"""
+        if not (0 < trans_state <= len(self._tuples)) or not (0 <= trans_index < self._state2id[trans_state + 1] - self._state2id[trans_state]):
+            raise KhgError("PairToTransitionId: out of range")
+        return self._state2id[trans_state] + trans_index
+
+    def transition_id_to_transition_state(self, trans_id: int) -> int:
+        self._chk(trans_id)
+        return self._id2state[trans_id]
+
+    def get_non_self_loop_log_prob(self, trans_state: int) -> float:
+        """csrc/transition-model.cc:515-518"""
+        return float(self._nsl[trans_state])
+
+    def get_transition_log_prob_ignoring_self_loops(self, trans_id: int) -> float:
+        """csrc/transition-model.cc:520-526 (float32 subtraction like the reference)"""
+        if self.is_self_loop(trans_id):
+            raise KhgError("GetTransitionLogProbIgnoringSelfLoops: self-loop")
+        return float(np.float32(self._log_probs[trans_id]) - np.float32(self._nsl[self._id2state[trans_id]]))
+
     # ---- statistics (csrc/transition-model.h:176-189) ----
     def init_stats(self) -> np.ndarray:
         return np.zeros(self.num_transition_ids + 1, np.float64)

@@ -1,0 +1,159 @@
+"""Training-graph builder + equal-align: structural contract of
+scripts/test_training_graph_compiler.py:85-105 (a valid path of exactly T transition-ids), the
+stochasticity of the compiled graph (path cost == -sum log P of its transitions and lexicon choices at
+scales 1.0), and -- on the GPU -- alignment of the compiled graphs against the oracle decoder."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def _setup(sil=True):
+    from kaldi_hmm_gmm_amd.context_dep import monophone_context_dependency
+    from kaldi_hmm_gmm_amd.training_graph import TrainingGraphCompiler, generate_hmm_topo
+    from kaldi_hmm_gmm_amd.transition_model import TransitionModel
+
+    topo = generate_hmm_topo([2, 3, 4], 1)                 # SIL=1, three real phones
+    cd = monophone_context_dependency(topo.phones, topo.get_phone_to_num_pdf_classes())
+    tm = TransitionModel(cd, topo)
+    lex = {1: [(1.0, [2])], 2: [(1.0, [3])], 3: [(0.7, [2, 4]), (0.3, [4])]}   # word 3 has two pronunciations
+    gc = TrainingGraphCompiler(tm, cd, lex, sil_phone=1 if sil else None)
+    return topo, cd, tm, gc
+
+
+def _walk(g, ali):
+    """All (state, cost) reachable by consuming `ali`; returns the cheapest accepting cost or None."""
+    cur = {g.start: 0.0}
+    for t in ali:
+        nxt = {}
+        for s, c in cur.items():
+            for a in g.arcs(s):
+                if a.ilabel == t:
+                    v = c + a.weight
+                    if v < nxt.get(a.nextstate, math.inf):
+                        nxt[a.nextstate] = v
+        cur = nxt
+        if not cur:
+            return None
+    best = None
+    for s, c in cur.items():
+        if g.is_final(s):
+            v = c + g.final(s)
+            best = v if best is None or v < best else best
+    return best
+
+
+def test_topology_and_sizes():
+    topo, cd, tm, gc = _setup()
+    assert topo.get_phone_to_num_pdf_classes() == [-1, 5, 3, 3, 3]      # scripts/prepare_lang.py:514-600
+    assert tm.num_pdfs == 5 + 9
+    g = gc.compile_graph_from_text([1, 2])
+    assert g.start == 0 and g.num_states > 0
+    # epsilon-free, every state's incoming arcs share one transition-state (AddSelfLoopsReorder's precondition)
+    cls = {}
+    for s in range(g.num_states):
+        for a in g.arcs(s):
+            assert a.ilabel != 0
+            if a.nextstate != s:
+                ts = tm.transition_id_to_transition_state(a.ilabel)
+                assert cls.setdefault(a.nextstate, ts) == ts
+    # the self-loop on a state is the self-loop of the transition-state entering it ("reorder")
+    for s in range(g.num_states):
+        for a in g.arcs(s):
+            if a.nextstate == s:
+                assert a.ilabel == tm.self_loop_of(cls[s]) and a.olabel == 0
+
+
+@pytest.mark.parametrize("sil", [True, False])
+def test_equal_align_contract_and_stochasticity(sil):
+    from kaldi_hmm_gmm_amd.training_graph import equal_align
+
+    topo, cd, tm, gc = _setup(sil)
+    logp = np.asarray(tm.log_probs, np.float64)
+    for seed, words in enumerate([[1], [1, 2], [2, 3, 1], [3, 3]]):
+        g = gc.compile_graph_from_text(words)
+        for T in (40, 97):
+            ok, ali = equal_align(g, T, rand_seed=seed + 3)
+            assert ok and len(ali) == T                                    # scripts/test_training_graph_compiler.py:85-105
+            cost = _walk(g, ali)
+            assert cost is not None, "equal_align produced a sequence the graph does not accept"
+            # path cost = -sum log P(transition) + lexicon costs: between (n+1)*log 2 ... with silence, pron costs for word 3
+            trans = -logp[ali].sum()
+            lexc = cost - trans
+            nsil = sum(1 for t in ali if tm.transition_id_to_phone(t) == 1 and tm.transition_id_to_hmm_state(t) == 0
+                       and not tm.is_self_loop(t))
+            want = (len(words) + 1) * math.log(2.0) if sil else 0.0
+            prons = [math.log(1 / 0.7), math.log(1 / 0.3)]
+            n3 = words.count(3)
+            cands = [want + sum(c) for c in ([()] if n3 == 0 else [(a,) for a in prons] if n3 == 1 else
+                                             [(a, b) for a in prons for b in prons])]
+            assert min(abs(lexc - c) for c in cands) < 1e-3, (words, lexc, cands, nsil)
+        # too short: fewer frames than emitting states on the shortest path
+        ok, _ = equal_align(g, 2)
+        assert not ok
+
+
+def test_words_and_min_length():
+    topo, cd, tm, gc = _setup(True)
+    g = gc.compile_graph_from_text([2, 1])
+    c = g.to_csr()
+    og = orc.OGraph(c["start"], c["arc_off"], c["ilabel"], c["olabel"], c["weight"], c["nextstate"], c["final"])
+    # a flat model: every pdf scores 0 -> the cheapest path is decided by the graph alone (no silence: 6 states)
+    id2pdf = np.asarray(tm.transition_id_to_pdf_array(), np.int32)
+    T = 12
+    npdf = tm.num_pdfs
+    res = orc.align_utterance_ll(og, id2pdf, T, np.arange(npdf, dtype=np.int32), np.zeros((npdf, T), np.float32),
+                                 acoustic_scale=1.0, beam=200.0, retry_beam=0.0)
+    assert res["status"] == 0 and res["words"].tolist() == [2, 1]
+    phones = [tm.transition_id_to_phone(int(t)) for t in res["ali"]]
+    assert 1 not in phones, "optional silence costs log 2 more than skipping it on a flat model"
+    res5 = orc.align_utterance_ll(og, id2pdf, 5, np.arange(npdf, dtype=np.int32), np.zeros((npdf, 5), np.float32),
+                                  acoustic_scale=1.0, beam=200.0, retry_beam=0.0)
+    assert res5["status"] & 1, "5 frames cannot cover 6 emitting states"
+
+
+@pytest.mark.gpu
+def test_compiled_graphs_align_like_oracle(ctx):
+    """Graphs with the 5-state silence (in-degree 4: the 3-bit register-resident Viterbi path) through the
+    reference-style entry points vs the oracle's FasterDecoder."""
+    import kaldi_hmm_gmm_amd as khg
+    from kaldi_hmm_gmm_amd import _gpu
+    from kaldi_hmm_gmm_amd.training_graph import equal_align
+
+    _gpu.set_default_context(ctx)
+    topo, cd, tm, gc = _setup(True)
+    rng = np.random.default_rng(11)
+    D = 8
+    allx = (rng.standard_normal((400, D)) * 2).astype(np.float32)
+    tm2, tree, am = khg.gmm_init_mono(topo, allx)
+    assert tm2.num_pdfs == tm.num_pdfs
+    means = (rng.standard_normal((tm.num_pdfs, D)) * 3).astype(np.float32)
+    for p in range(tm.num_pdfs):
+        gm = am.get_pdf(p); gm.set_means(means[p][None, :]); gm.compute_gconsts()
+    go, gcst, w, miv, iv = am.flat()
+    om = orc.OModel(go, gcst, miv, iv)
+    id2pdf = np.asarray(tm.transition_id_to_pdf_array(), np.int32)
+    names, fsts, feats = [], [], []
+    for u, words in enumerate([[1, 2], [3], [2, 3, 1], [1, 1, 2, 3]]):
+        g = gc.compile_graph_from_text(words)
+        T = 30 + 17 * u
+        ok, ali = equal_align(g, T, rand_seed=u)
+        assert ok
+        x = np.stack([means[id2pdf[t]] for t in ali]).astype(np.float32) + rng.standard_normal((T, D)).astype(np.float32)
+        names.append(f"u{u}"); fsts.append(g); feats.append(x)
+    for beam, retry in ((200.0, 0.0), (6.0, 40.0)):
+        cfg = khg.AlignConfig(beam=beam, retry_beam=retry)
+        rb = khg.gmm_align_compiled_batch(am, tm, names, [f.copy() for f in fsts], feats, cfg, acoustic_scale=0.1,
+                                          transition_scale=1.0, self_loop_scale=0.1)
+        cost = tm.scaled_trans_cost(1.0, 0.1)
+        for u, g in enumerate(fsts):
+            c = g.to_csr()
+            wgt = np.where(c["ilabel"] >= 1, c["weight"] + cost[np.maximum(c["ilabel"], 0)], c["weight"]).astype(np.float32)
+            og = orc.OGraph(c["start"], c["arc_off"], c["ilabel"], c["olabel"], wgt, c["nextstate"], c["final"])
+            want = orc.align_utterance(og, om, id2pdf, feats[u], acoustic_scale=0.1, beam=beam, retry_beam=retry)
+            assert want["status"] & 1 == 0
+            assert rb["alignment"][u] == want["ali"].tolist(), (beam, u)
+            assert rb["words"][u] == want["words"].tolist()
+        assert rb["num_done"] == len(fsts) and rb["num_error"] == 0
