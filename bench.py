@@ -244,7 +244,22 @@ def main():
     k1_flops_per_launch = k1_flops / nb
 
     if rank == 0:
+        tm0 = time.perf_counter()
         res = accs.download()
+        tm1 = time.perf_counter()
+        # the host M-step of the same iteration, timed separately ("M-step reported separately"):
+        # accumulator download -> MleAmDiagGmmUpdate + ComputeGconsts (host C++, fp64) -> new model upload
+        from kaldi_hmm_gmm_amd import mle as _mle
+        mo = _mle.MleDiagGmmOptions()
+        r_up = _mle._flat_update(mo, model.gauss_off, res["occ"], res["mean_acc"], res["var_acc"], 7, 7, model.weights,
+                                 model.means_invvars, model.inv_vars)
+        tm2 = time.perf_counter()
+        dm2 = DeviceModel(ctxs[0], r_up[0], r_up[2], r_up[3], r_up[4])
+        ctxs[0].sync()
+        tm3 = time.perf_counter()
+        dm2.close()
+        m_step = {"accs_download_ms": (tm1 - tm0) * 1e3, "host_update_ms": (tm2 - tm1) * 1e3, "model_upload_ms": (tm3 - tm2) * 1e3,
+                  "gaussians_after": int(r_up[0][-1]), "note": "not part of value; host C++ update threaded over pdfs, tile image packed on the device"}
         traffic, traffic_src = pmc_traffic(frames_local / nb)
         out = {
             "metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss",
@@ -269,6 +284,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
+            "m_step": m_step,
             "check": {"acc_total_frames": res["total_frames"] , "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
         }

@@ -151,6 +151,40 @@ static int check_err_flag(khg_ctx* c, const char* where) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K0: pack the K1 tile image from the row-major parameters (one workgroup per W tile).
+// planes q = 0..3 of [32][ROW]: q=0/1: means_invvars at even/odd d, q=2/3: -0.5*inv_vars (exact
+// scaling) at even/odd d, element s of a row <-> d = 2s + (q&1); then gconst[32].  Padding rows:
+// W = 0, gconst = -inf (they contribute exp2(-inf) = 0 to the log-sum-exp).  Also writes the
+// row-major -0.5*inv_vars copy K3 uses.
+template <int KQ>
+__global__ __launch_bounds__(256) void k0_pack_tiles(const float* __restrict__ gconsts, const float* __restrict__ miv,
+                                                      const float* __restrict__ iv, const int32_t* __restrict__ gauss_off,
+                                                      const int32_t* __restrict__ pdf_tile_off, const int32_t* __restrict__ tile_pdf,
+                                                      int D, float* __restrict__ wimg, float* __restrict__ nhiv) {
+  constexpr int ROW = khg_row_floats(KQ), TILE = khg_tile_floats(KQ);
+  const int t = blockIdx.x, p = tile_pdf[t];
+  const int g_first = gauss_off[p] + 32 * (t - pdf_tile_off[p]);
+  const int nrow = min(32, gauss_off[p + 1] - g_first);
+  float* img = wimg + (size_t)t * TILE;
+  for (int i = threadIdx.x; i < TILE; i += 256) {
+    float v = 0.0f;
+    if (i < 4 * 32 * ROW) {
+      const int q = i / (32 * ROW), r = (i / ROW) & 31, s = i % ROW;
+      const int d = 2 * s + (q & 1);
+      if (r < nrow && d < D) {
+        const size_t src = (size_t)(g_first + r) * D + d;
+        v = (q & 2) ? -0.5f * iv[src] : miv[src];
+      }
+    } else if (i < 4 * 32 * ROW + 32) {
+      const int r = i - 4 * 32 * ROW;
+      v = r < nrow ? gconsts[g_first + r] : -INFINITY;
+    }
+    img[i] = v;
+  }
+  for (int i = threadIdx.x; i < nrow * D; i += 256) nhiv[(size_t)g_first * D + i] = -0.5f * iv[(size_t)g_first * D + i];
+}
+
+// ------------------------------------------------------------------------------------------
 struct khg_model {
   khg_ctx* ctx = nullptr;
   int32_t P = 0, D = 0, KQ = 0, ntiles = 0;
@@ -180,37 +214,38 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
   for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (gauss_off[p + 1] - gauss_off[p] + 31) / 32; }
   m->pdf_tile_off[P] = nt;
   m->ntiles = nt;
-  // tile image: planes q = 0..3 of [32][ROW]: q=0/1: means_invvars at even/odd d, q=2/3: -0.5*inv_vars
-  // (exact scaling) at even/odd d, element s of a row <-> d = 2s + (q&1); then gconst[32].  Padding
-  // rows: W = 0, gconst = -inf (they contribute exp(-inf) = 0 to the log-sum-exp)
-  const int ROW = khg_row_floats(m->KQ), TILE = khg_tile_floats(m->KQ);
-  std::vector<float> img((size_t)nt * TILE, 0.0f);
-  for (int p = 0; p < P; ++p) {
-    int G = gauss_off[p + 1] - gauss_off[p];
-    for (int g = 0; g < ((G + 31) / 32) * 32; ++g) {
-      float* t = img.data() + (size_t)(m->pdf_tile_off[p] + g / 32) * TILE;
-      int r = g % 32;
-      if (g < G) {
-        const float* mi = miv + (size_t)(gauss_off[p] + g) * D;
-        const float* v = iv + (size_t)(gauss_off[p] + g) * D;
-        for (int d = 0; d < D; ++d) {
-          t[((d & 1) * 32 + r) * ROW + (d >> 1)] = mi[d];
-          t[((2 + (d & 1)) * 32 + r) * ROW + (d >> 1)] = -0.5f * v[d];
-        }
-        t[4 * 32 * ROW + r] = gconsts[gauss_off[p] + g];
-      } else {
-        t[4 * 32 * ROW + r] = -INFINITY;
-      }
-    }
-  }
-  int rc = dev_upload(ctx, &m->wimg_d, img);
-  if (!rc) rc = dev_upload(ctx, &m->pdf_tile_off_d, m->pdf_tile_off);
+  // The row-major parameters go up as they are (K3 reads them); the K1 tile image and the -0.5*inv_vars
+  // copy are packed from them ON THE DEVICE (k0_pack_tiles) -- no host-side 113 MB image, no extra copies.
+  const int TILE = khg_tile_floats(m->KQ);
+  int rc = dev_upload(ctx, &m->pdf_tile_off_d, m->pdf_tile_off);
   if (!rc) rc = dev_upload(ctx, &m->gauss_off_d, m->gauss_off);
-  std::vector<float> tmp;
-  if (!rc) { tmp.assign(gconsts, gconsts + m->sumG); rc = dev_upload(ctx, &m->gconsts_d, tmp); }
-  if (!rc) { tmp.assign(miv, miv + m->sumG * D); rc = dev_upload(ctx, &m->miv_d, tmp); }
-  if (!rc) { tmp.assign(iv, iv + m->sumG * D); rc = dev_upload(ctx, &m->iv_d, tmp); }
-  if (!rc) { for (auto& x : tmp) x = -0.5f * x; rc = dev_upload(ctx, &m->nhiv_d, tmp); }
+  auto up = [&](float** dst, const float* src, size_t n) -> int {
+    int r = dev_alloc(dst, n);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(*dst, src, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    return KHG_OK;
+  };
+  if (!rc) rc = up(&m->gconsts_d, gconsts, (size_t)m->sumG);
+  if (!rc) rc = up(&m->miv_d, miv, (size_t)m->sumG * D);
+  if (!rc) rc = up(&m->iv_d, iv, (size_t)m->sumG * D);
+  if (!rc) rc = dev_alloc(&m->nhiv_d, (size_t)m->sumG * D);
+  if (!rc) rc = dev_alloc(&m->wimg_d, (size_t)nt * TILE);
+  if (!rc) {
+    // tile -> pdf map for the pack kernel
+    std::vector<int32_t> tile_pdf((size_t)nt);
+    for (int p = 0; p < P; ++p)
+      for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
+    int32_t* tile_pdf_d = nullptr;
+    rc = dev_upload(ctx, &tile_pdf_d, tile_pdf);
+    if (!rc) {
+      if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+      else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // tile_pdf (host) and the caller's arrays are free after this
+      if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    }
+    DEVFREE(tile_pdf_d);
+  }
   if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
   if (rc) { khg_model_destroy(m); return rc; }
   *out = m;

@@ -5,7 +5,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/khg_hip.h"
@@ -162,29 +164,60 @@ extern "C" int khg_mle_am_diag_gmm_update(const khg_mle_options* o, int32_t P, i
   if (flags & ~acc_flags) return khg_set_error(KHG_E_RUNTIME, "Flags in argument do not match the active accumulators");  // mle-diag-gmm.cc:252
   if ((acc_flags & kMeans) && !mean_acc) return khg_set_error(KHG_E_ARG, "mean accumulator missing");
   if ((acc_flags & kVars) && !var_acc) return khg_set_error(KHG_E_ARG, "variance accumulator missing");
-  // csrc/mle-am-diag-gmm.cc:153-202: float running totals
+  // Pdfs are independent (csrc/mle-am-diag-gmm.cc:177-193 loops over them): each host thread updates a
+  // contiguous range IN PLACE at the pdf's original offset (a pdf never grows), then one sequential pass
+  // compacts the arrays and adds the per-pdf statistics in pdf order with the reference's float totals
+  // (:153-202), so results do not depend on the thread count.
+  std::vector<UpdateResult> res((size_t)P);
+  std::vector<int32_t> newG((size_t)P, 0);
+  std::vector<uint8_t> bad((size_t)P, 0);
+  int nthr = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("KHG_HOST_THREADS")) nthr = atoi(e);
+  nthr = std::max(1, std::min(nthr, 64));
+  if ((int64_t)gauss_off[P] * D < (1 << 16)) nthr = 1;
+  nthr = std::min(nthr, P);
+  auto work = [&](int p0, int p1) {
+    std::vector<float> w, gc, miv, iv;
+    for (int p = p0; p < p1; ++p) {
+      const int g0 = gauss_off[p], G = gauss_off[p + 1] - g0;
+      w.assign(weights + g0, weights + g0 + G);
+      gc.assign(G, 0.0f);
+      miv.assign(means_invvars + (size_t)g0 * D, means_invvars + (size_t)(g0 + G) * D);
+      iv.assign(inv_vars + (size_t)g0 * D, inv_vars + (size_t)(g0 + G) * D);
+      if (!MleUpdateOne(*o, D, occ + g0, mean_acc ? mean_acc + (size_t)g0 * D : nullptr,
+                        var_acc ? var_acc + (size_t)g0 * D : nullptr, acc_flags, flags, w, gc, miv, iv, &res[p])) {
+        bad[p] = 1;
+        continue;
+      }
+      newG[p] = (int32_t)w.size();
+      std::copy(w.begin(), w.end(), weights + g0);
+      std::copy(gc.begin(), gc.end(), gconsts + g0);
+      std::copy(miv.begin(), miv.end(), means_invvars + (size_t)g0 * D);
+      std::copy(iv.begin(), iv.end(), inv_vars + (size_t)g0 * D);
+    }
+  };
+  if (nthr == 1) {
+    work(0, P);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; ++t) th.emplace_back(work, (int)((int64_t)P * t / nthr), (int)((int64_t)P * (t + 1) / nthr));
+    for (auto& t : th) t.join();
+  }
   float tot_obj = 0.0f, tot_count = 0.0f;
   int tfe = 0, tfg = 0, trm = 0;
   int out = 0;
-  std::vector<float> w, gc, miv, iv;
   for (int p = 0; p < P; ++p) {
-    const int g0 = gauss_off[p], G = gauss_off[p + 1] - g0;
-    w.assign(weights + g0, weights + g0 + G);
-    gc.assign(G, 0.0f);
-    miv.assign(means_invvars + (size_t)g0 * D, means_invvars + (size_t)(g0 + G) * D);
-    iv.assign(inv_vars + (size_t)g0 * D, inv_vars + (size_t)(g0 + G) * D);
-    UpdateResult r;
-    if (!MleUpdateOne(*o, D, occ + g0, mean_acc ? mean_acc + (size_t)g0 * D : nullptr,
-                      var_acc ? var_acc + (size_t)g0 * D : nullptr, acc_flags, flags, w, gc, miv, iv, &r))
-      return khg_set_error(KHG_E_RUNTIME, "pdf " + std::to_string(p) + ": not a number in gconst computation");
+    if (bad[p]) return khg_set_error(KHG_E_RUNTIME, "pdf " + std::to_string(p) + ": not a number in gconst computation");
+    const UpdateResult& r = res[p];
     tot_obj += r.obj_change; tot_count += r.count; tfe += r.floored_elems; tfg += r.floored_gauss; trm += r.removed;
-    const int Gn = (int)w.size();
+    const int g0 = gauss_off[p], Gn = newG[p];
     new_gauss_off[p] = out;
-    // compaction is in place and never overtakes the read cursor (out <= g0)
-    std::copy(w.begin(), w.end(), weights + out);
-    std::copy(gc.begin(), gc.end(), gconsts + out);
-    std::copy(miv.begin(), miv.end(), means_invvars + (size_t)out * D);
-    std::copy(iv.begin(), iv.end(), inv_vars + (size_t)out * D);
+    if (out != g0) {   // compaction never overtakes the read cursor (out <= g0)
+      std::memmove(weights + out, weights + g0, sizeof(float) * Gn);
+      std::memmove(gconsts + out, gconsts + g0, sizeof(float) * Gn);
+      std::memmove(means_invvars + (size_t)out * D, means_invvars + (size_t)g0 * D, sizeof(float) * (size_t)Gn * D);
+      std::memmove(inv_vars + (size_t)out * D, inv_vars + (size_t)g0 * D, sizeof(float) * (size_t)Gn * D);
+    }
     out += Gn;
   }
   new_gauss_off[P] = out;
