@@ -147,6 +147,74 @@ class HmmTopology:
         out.append("</Topology> \n")
         return "".join(out)
 
+    # ---- stream I/O (csrc/hmm-topology.cc:23-282), text and binary ----
+    def _write(self, w) -> None:
+        if not w.binary:
+            w.raw(str(self))
+            return
+        hmm = self.is_hmm
+        w.token("<Topology>")
+        w.int_vector(self._phones)
+        w.int_vector(self._phone2idx)
+        if not hmm:
+            w.int32(-1)                 # marks the extended format with SelfLoopPdfClass
+        w.int32(len(self._entries))
+        for entry in self._entries:
+            w.int32(len(entry))
+            for st in entry:
+                w.int32(st.forward_pdf_class)
+                if not hmm:
+                    w.int32(st.self_loop_pdf_class)
+                w.int32(len(st.transitions))
+                for dst, pr in st.transitions:
+                    w.int32(dst)
+                    w.float32(pr)
+        w.token("</Topology>")
+
+    def _read(self, r) -> None:
+        if not r.binary:
+            # text: hand the <Topology> ... </Topology> span to the token parser
+            r._skip_ws()
+            end = r.d.find(b"</Topology>", r.i)
+            if end < 0:
+                raise KhgError("Reading HmmTopology object, </Topology> not found")
+            end += len(b"</Topology>")
+            self.read(r.d[r.i:end].decode("ascii"))
+            r.i = min(end + 1, len(r.d))
+            return
+        import numpy as np
+        r.expect("<Topology>")
+        self._phones = r.int_vector()
+        self._phone2idx = r.int_vector()
+        n = r.int32()
+        hmm = True
+        if n == -1:
+            hmm = False
+            n = r.int32()
+        self._entries = []
+        for _ in range(n):
+            entry = []
+            for _ in range(r.int32()):
+                fwd = r.int32()
+                st = HmmState(fwd, fwd if hmm else r.int32())
+                for _ in range(r.int32()):
+                    dst = r.int32()
+                    st.transitions.append((dst, float(np.float32(r.float32()))))
+                entry.append(st)
+            self._entries.append(entry)
+        r.expect("</Topology>")
+        self.check()
+
+    def write(self, binary: bool, filename: str) -> None:
+        from . import kaldi_io
+        w = kaldi_io.Writer(binary)
+        self._write(w)
+        kaldi_io.write_file(filename, binary, w.getvalue())
+
+    def read_file(self, filename: str) -> None:
+        from . import kaldi_io
+        self._read(kaldi_io.read_file(filename))
+
     # ---- accessors ----
     @property
     def phones(self) -> List[int]:

@@ -10,6 +10,20 @@ from . import _lib
 from ._lib import KhgError, check, lib, ptr
 from .hmm_topology import HmmTopology, kNoPdf
 
+_libm = C.CDLL("libm.so.6")
+_libm.expf.restype = C.c_float
+_libm.expf.argtypes = [C.c_float]
+_libm.logf.restype = C.c_float
+_libm.logf.argtypes = [C.c_float]
+
+
+def _libm_expf(x: float) -> float:
+    return _libm.expf(x)
+
+
+def _libm_logf(x: float) -> float:
+    return _libm.logf(x)
+
 
 class MleTransitionUpdateConfig:
     """csrc/transition-model.h:80-92."""
@@ -133,11 +147,12 @@ class TransitionModel:
             if tid == 0:
                 nsl[ts] = 0.0
             else:
-                slp = np.exp(self._log_probs[tid], dtype=np.float32)
+                # libm's float expf / logf, exactly what the C++ update (khg_transition_mle_update) calls
+                slp = _libm_expf(float(self._log_probs[tid]))
                 p = np.float32(1.0 - float(slp))
                 if p <= 0.0:
                     p = np.float32(1.0e-10)
-                nsl[ts] = np.log(p)
+                nsl[ts] = _libm_logf(float(p))
         self._nsl = nsl
 
     def check(self):
@@ -313,6 +328,61 @@ class TransitionModel:
                                         ptr(i2s, C.c_int32), ptr(sl, C.c_uint8), C.c_float(transition_scale),
                                         C.c_float(self_loop_scale), ptr(out, C.c_float)))
         return out
+
+    # ---- stream I/O (csrc/transition-model.cc:37-116), text and binary ----
+    def _write(self, w) -> None:
+        if not w.binary:
+            w.raw(str(self))
+            return
+        hmm = self._topo.is_hmm
+        w.token("<TransitionModel>")
+        self._topo._write(w)
+        w.token("<Triples>" if hmm else "<Tuples>")
+        w.int32(len(self._tuples))
+        for t in self._tuples:
+            w.int32(t.phone); w.int32(t.hmm_state); w.int32(t.forward_pdf)
+            if not hmm:
+                w.int32(t.self_loop_pdf)
+        w.token("</Triples>" if hmm else "</Tuples>")
+        w.token("<LogProbs>")
+        w.float_vector(self._log_probs)
+        w.token("</LogProbs>")
+        w.token("</TransitionModel>")
+
+    def _read(self, r) -> None:
+        r.expect("<TransitionModel>")
+        self._topo = HmmTopology()
+        self._topo._read(r)
+        tok = r.token()
+        if tok not in ("<Triples>", "<Tuples>"):
+            raise KhgError(f"TransitionModel::Read, unexpected token {tok}")
+        n = r.int32()
+        self._tuples = []
+        for _ in range(n):
+            ph, hs, fp = r.int32(), r.int32(), r.int32()
+            self._tuples.append(TransitionModelTuple(ph, hs, fp, r.int32() if tok == "<Tuples>" else fp))
+        end = r.token()
+        if end not in ("</Triples>", "</Tuples>"):
+            raise KhgError(f"TransitionModel::Read, unexpected token {end}")
+        self._compute_derived()
+        r.expect("<LogProbs>")
+        self._log_probs = np.asarray(r.float_vector(), np.float32).copy()
+        r.expect("</LogProbs>")
+        r.expect("</TransitionModel>")
+        if self._log_probs.shape[0] != self.num_transition_ids + 1:
+            raise KhgError("TransitionModel::Read: <LogProbs> size does not match the tuples")
+        self._compute_derived_of_probs()
+        self.check()
+
+    def write(self, binary: bool, filename: str) -> None:
+        from . import kaldi_io
+        w = kaldi_io.Writer(binary)
+        self._write(w)
+        kaldi_io.write_file(filename, binary, w.getvalue())
+
+    def read(self, filename: str) -> None:
+        from . import kaldi_io
+        self._read(kaldi_io.read_file(filename))
 
     def __str__(self):  # csrc/transition-model.cc:37-83 text Write
         out = ["<TransitionModel> \n", str(self._topo), "<Triples> ", f"{len(self._tuples)} \n"]
