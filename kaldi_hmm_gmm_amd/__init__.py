@@ -5,8 +5,9 @@ pybind11 module `kaldi_hmm_gmm` (python/kaldi_hmm_gmm/__init__.py) and of its sc
 Importing this package loads libkhg_hip.so; there is no CPU fallback."""
 from . import _lib  # noqa: F401  (fails loudly when libkhg_hip.so is missing)
 from ._lib import KhgError  # noqa: F401
-from .align import (AlignConfig, DecodableAmDiagGmmScaled, DecodableAmDiagGmmUnmapped, FasterDecoderOptions,  # noqa: F401
-                    add_transition_probs, align_batch, align_utterance_wrapper)
+from .align import (AlignConfig, DecodableAmDiagGmmScaled, DecodableAmDiagGmmUnmapped, FasterDecoder,  # noqa: F401
+                    FasterDecoderOptions, LatticeArc, LatticeWeight, LinearLattice, add_transition_probs, align_batch,
+                    align_utterance_wrapper)
 from .context_dep import ContextDependency, monophone_context_dependency, monophone_context_dependency_shared  # noqa: F401
 from .device import (ALIGN_DONE, ALIGN_ERROR, ALIGN_EXACT_DP, ALIGN_FALLBACK, ALIGN_RETRIED, Context, DeviceAccs,  # noqa: F401
                      DeviceModel, DeviceTransitions, UtteranceSet)

@@ -320,3 +320,35 @@ def test_bad_configs_raise(ctx):
     with pytest.raises(khg.KhgError):          # hmm-utils.cc:484-488 invalid symbol on graph input side
         from kaldi_hmm_gmm_amd import UtteranceSet
         UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=bad)
+
+
+def test_faster_decoder_class_like_reference_binding(khg):
+    """python/csrc/faster-decoder.cc:33-53: decode / reached_final / get_best_path on the GPU path vs the
+    oracle's FasterDecoder (best path labels and the LatticeWeight total of csrc/decoder-wrappers.cc:93-95)."""
+    topo, tm, tree, am, utts = _mini_problem(khg)
+    go, gc, w, miv, iv = am.flat()
+    om = orc.OModel(go, gc, miv, iv)
+    id2pdf = np.asarray(tm.transition_id_to_pdf_array(), np.int32)
+    opts = khg.FasterDecoderOptions(beam=16.0)
+    for name, fst, feats, ali_ref, words in utts[:3]:
+        g = fst.copy()
+        khg.add_transition_probs(tm, [], 1.0, 0.1, g)
+        dec = khg.FasterDecoder(g, opts)
+        assert dec.num_frames_decoded() == -1
+        dec.decode(khg.DecodableAmDiagGmmScaled(am, tm, feats, 0.1))
+        assert dec.reached_final() and dec.num_frames_decoded() == feats.shape[0]
+        ok, lat = dec.get_best_path()
+        assert ok and lat.num_states == feats.shape[0] + 1
+        ok, il, ol, wt = lat.get_linear_symbol_sequence()
+        c = g.to_csr()
+        og = orc.OGraph(c["start"], c["arc_off"], c["ilabel"], c["olabel"], c["weight"], c["nextstate"], c["final"])
+        want = orc.align_utterance(og, om, id2pdf, feats, acoustic_scale=0.1, beam=16.0)
+        assert il == want["ali"].tolist() == ali_ref and ol == want["words"].tolist()
+        assert -(wt.value1 + wt.value2) / 0.1 == pytest.approx(want["like"], rel=1e-5)
+    # a graph whose final state cannot be reached in T frames: no best path on this path
+    name, fst, feats, _, _ = utts[0]
+    dec = khg.FasterDecoder(fst.copy(), opts)
+    dec.decode(khg.DecodableAmDiagGmmScaled(am, tm, feats[:2], 0.1))
+    assert not dec.reached_final() and dec.get_best_path()[0] is False
+    with pytest.raises(khg.KhgError):
+        khg.FasterDecoder(fst, khg.FasterDecoderOptions(max_active=1))
