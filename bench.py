@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batches", type=int, default=1, help="utterance batches per rank (more batches bound the score/back-pointer buffers and let a batch's serial fallback decoder overlap the next batch's K1)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
+    ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
     ap.add_argument("--seed", type=int, default=20230418)
     return ap.parse_args()
 
@@ -188,6 +189,16 @@ def main():
     npdf = np.concatenate([np.diff(s_.pdf_lists()[0]) for s_ in sets])
     frames_local = int(ut.frame_off[-1])
     k1_flops = float((T * npdf).sum()) * (4.0 * D * G + 5.0 * G)  # alignment log-likes
+    # cells K1 leaves out with khg_loglikes_reachable: whole 16-frame tiles before a pdf's first readable frame
+    # (at most the first 2 tiles of each wave = 8 tiles are dropped by the compiled variants) -- an estimate
+    skipped_cells = 0.0
+    if not args.full_loglikes:
+        for s_ in sets:
+            poff_, _ = s_.pdf_lists()
+            first = s_.pdf_first_frames().astype(np.int64)
+            Tu = np.repeat(np.diff(s_.frame_off), np.diff(poff_))
+            skipped_cells += float(np.minimum(16 * np.minimum(first // 16, 8), Tu).sum())
+    k1_exec_frac = 1.0 - skipped_cells / max(float((T * npdf).sum()), 1.0)
     kernel_ms = {}
     ev_a = torch.cuda.Event()
     ev_b = torch.cuda.Event()
@@ -198,7 +209,7 @@ def main():
         for st in streams[1:]:
             st.wait_event(ev_a)
         for s_ in sets:                               # batches alternate between the two streams
-            s_.loglikes(dm)
+            s_.loglikes(dm, reachable_only=not args.full_loglikes)
             s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=False)
         for s_ in sets:
             s_.acc_stats(dm, tm, accs)
@@ -282,6 +293,10 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "executed_cell_fraction": k1_exec_frac,
+                         "note": "achieved/frac use the dense T x P_u contract FLOPs of SURVEY 8(d); K1 evaluates only the "
+                                 "(frame, pdf) cells a decoder token can read (executed_cell_fraction of them, estimate); "
+                                 "executed TFLOP/s = achieved x executed_cell_fraction",
                          "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
             "m_step": m_step,

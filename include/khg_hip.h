@@ -88,6 +88,9 @@ int khg_utts_destroy(khg_utts *u);
 /* number of distinct pdfs on each utterance's graph, and the list itself (sorted) */
 int khg_utts_num_pdfs(const khg_utts *u, int64_t *pdf_off_h /* [n_utt+1] */);
 int khg_utts_pdfs(const khg_utts *u, int32_t *pdfs_h /* [pdf_off[n_utt]] */);
+/* per listed pdf: the first frame a decoder token can read it at (fewest emitting arcs from the start state
+ * to an arc carrying it; INT32_MAX if never; 0 for sets without graphs) -- what khg_loglikes_reachable uses */
+int khg_utts_pdf_first(const khg_utts *u, int32_t *first_h /* [pdf_off[n_utt]] */);
 
 /* ---- K1: log-likelihoods --------------------------------------------------------------- */
 /* DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased (csrc/decodable-am-diag-gmm.cc:29-71) for
@@ -96,6 +99,13 @@ int khg_utts_pdfs(const khg_utts *u, int32_t *pdfs_h /* [pdf_off[n_utt]] */);
  * tpad = T rounded up to 32, j = index into the utterance's pdf list.  KHG_E_RUNTIME if any
  * value is NaN/Inf (the reference throws, :63-65). */
 int khg_loglikes(khg_ctx *ctx, const khg_model *m, khg_utts *u);
+/* Same, restricted to the (frame, pdf) cells the decoder can read: DecodableAmDiagGmmScaled only
+ * evaluates LogLikelihood(frame, tid) for tokens that exist (csrc/faster-decoder.cc:208), and no token
+ * can sit in a state before as many frames as the fewest emitting arcs from the start state lead to
+ * it.  Cells of a pdf in 16-frame tiles that end before that are left untouched (unspecified
+ * contents); alignments are identical to khg_loglikes + khg_align.  Sets without graphs: same as
+ * khg_loglikes. */
+int khg_loglikes_reachable(khg_ctx *ctx, const khg_model *m, khg_utts *u);
 /* total floats of the resident ll buffer and per-utterance offsets [n_utt+1] */
 int khg_loglikes_layout(const khg_utts *u, int64_t *ll_off_h, int64_t *total);
 int khg_loglikes_download(khg_ctx *ctx, const khg_utts *u, float *ll_h);

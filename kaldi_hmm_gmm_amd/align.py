@@ -134,7 +134,7 @@ def align_batch(am: AmDiagGmm, tm: TransitionModel, fsts: List[StdVectorFst], fe
     if feats.shape[0] == 0:
         feats = np.zeros((1, am.dim), np.float32)[:0]
     us = UtteranceSet(ctx, dt, frame_off, feats if feats.shape[0] else np.zeros((0, am.dim), np.float32), graphs=concat_graphs(fsts))
-    us.loglikes(dm)
+    us.loglikes(dm, reachable_only=True)      # only the cells a decoder token can read (khg_loglikes_reachable)
     o = decoder_opts or FasterDecoderOptions()
     res = us.align(dt, beam=config.beam, retry_beam=config.retry_beam, acoustic_scale=acoustic_scale,
                    careful=config.careful, max_active=o.max_active, min_active=o.min_active, beam_delta=o.beam_delta,

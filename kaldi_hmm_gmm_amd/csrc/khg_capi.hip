@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
+#include <deque>
 #include <vector>
 
 #include "../../include/khg_hip.h"
@@ -319,6 +321,8 @@ struct khg_utts {
   // K1
   K1Chunk* chunks_d = nullptr; int32_t n_chunks = 0; int32_t chunk_kq = 0;
   int64_t* tile_off_d = nullptr; int32_t* tiles_d = nullptr;
+  std::vector<int32_t> pdf_first;  // per (utterance, listed pdf): first frame at which any state emitting it can hold a token
+  int tiles_reach = -1;            // whether the walk lists carry those first frames (reachable-only K1) or zeros
   std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
   float* ll_d = nullptr; int64_t ll_total = 0; bool ll_valid = false;
   // K2 scratch / outputs
@@ -412,6 +416,37 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
       if (tmp_pdfs.size() > 32767) return fail(KHG_E_UNSUPPORTED, "khg_utts_create: more than 32767 distinct pdfs on one decoding graph");
       u->pdf_off[i + 1] = u->pdf_off[i] + (int64_t)tmp_pdfs.size();
       u->pdfs.insert(u->pdfs.end(), tmp_pdfs.begin(), tmp_pdfs.end());
+      {
+        // first frame each listed pdf can be needed at: a token can sit in state s after no fewer than
+        // dmin[s] emitting arcs (0-1 BFS from the start state), so the score of an arc's pdf is first
+        // read at frame dmin[src].  K1 may skip (pdf, frame) cells before that (khg_loglikes_reachable).
+        std::vector<int32_t> dmin((size_t)S, INT32_MAX);
+        std::vector<int32_t> dq;
+        if (start[i] >= 0) {
+          std::deque<int32_t> q;
+          dmin[start[i]] = 0; q.push_back(start[i]);
+          while (!q.empty()) {
+            const int s = q.front(); q.pop_front();
+            for (int64_t a = arc_off[s0 + s]; a < arc_off[s0 + s + 1]; ++a) {
+              const int d = nextstate[a], wgt = ilabel[a] >= 1 ? 1 : 0;
+              if (dmin[s] + wgt < dmin[d]) {
+                dmin[d] = dmin[s] + wgt;
+                if (wgt) q.push_back(d); else q.push_front(d);
+              }
+            }
+          }
+        }
+        const size_t base = u->pdf_first.size();
+        u->pdf_first.resize(base + tmp_pdfs.size(), INT32_MAX);
+        for (int64_t s = 0; s < S; ++s) {
+          if (dmin[s] == INT32_MAX) continue;
+          for (int64_t a = arc_off[s0 + s]; a < arc_off[s0 + s + 1]; ++a) {
+            if (ilabel[a] < 1) continue;
+            const size_t j = (size_t)(std::lower_bound(tmp_pdfs.begin(), tmp_pdfs.end(), tm->id2pdf[ilabel[a]]) - tmp_pdfs.begin());
+            u->pdf_first[base + j] = std::min(u->pdf_first[base + j], dmin[s]);
+          }
+        }
+      }
       // in-arc CSR: stable bucketing by destination (ties in the DP then resolve to the lowest
       // original arc index, like a strict '<' scan over arcs in file order)
       for (int64_t a = a0; a < a1; ++a) in_off[s0 + nextstate[a] + 1]++;
@@ -471,10 +506,11 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   if (!u || n <= 0 || !pdfs) return khg_set_error(KHG_E_ARG, "khg_utts_set_pdf_list: bad arguments");
   if (u->has_graphs) return khg_set_error(KHG_E_ARG, "khg_utts_set_pdf_list: set has graphs; its pdf lists come from them");
   u->pdfs.clear();
+  u->pdf_first.clear();     // no graphs behind an explicit list: every frame is needed
   for (int i = 0; i < u->n_utt; ++i) { u->pdf_off[i + 1] = u->pdf_off[i] + n; u->pdfs.insert(u->pdfs.end(), pdfs, pdfs + n); }
   plan_ll(u);
   DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d);
-  DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear();
+  DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear(); u->tiles_reach = -1;
   u->ll_valid = false;
   return KHG_OK;
 }
@@ -522,8 +558,9 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
 // 16-frame tiles per wave: 6 x 20 B-operand VGPRs fit 2 waves/SIMD at D <= 40 (KHG_K1_NF=5 selects the smaller chunk)
 static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); return KQ != 10 ? 5 : (e && atoi(e) == 5) ? 5 : 6; }
 
-extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
+static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
+  if (u->pdf_first.size() != u->pdfs.size()) reachable_only = false;
   if (m->D != u->D) return khg_set_error(KHG_E_RUNTIME, "Dim mismatch: data dim = " + std::to_string(u->D) + " vs. model dim = " + std::to_string(m->D));
   for (int32_t p : u->pdfs)
     if (p < 0 || p >= m->P) return khg_set_error(KHG_E_RUNTIME, "Likely graph/model mismatch, e.g. using wrong HCLG.fst (pdf-id " + std::to_string(p) + ")");
@@ -559,18 +596,22 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
   }
-  if (u->tiles_pto != m->pdf_tile_off) {
+  if (u->tiles_pto != m->pdf_tile_off || u->tiles_reach != (int)reachable_only) {
     // per-utterance W-tile walk for this model's tile layout (it only changes when the number of
     // Gaussians of some pdf crosses a multiple of 32): for every pdf on the utterance's list its
-    // tiles in order, bit 31 marking the last tile of a pdf
+    // tiles in order.  Entry = tile id (bits 0-21) | first needed 16-frame tile of the pdf, clamped
+    // to 127 (bits 22-28; 0 unless reachable_only) | last-tile-of-pdf flag (bit 31).
+    if (m->ntiles >= (1 << 22)) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: more than 4M W tiles");
     DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
     std::vector<int64_t> toff((size_t)u->n_utt + 1, 0);
     std::vector<int32_t> tiles;
     for (int i = 0; i < u->n_utt; ++i) {
       for (int64_t k = u->pdf_off[i]; k < u->pdf_off[i + 1]; ++k) {
         const int p = u->pdfs[(size_t)k];
+        int ef = 0;
+        if (reachable_only) ef = (int)std::min<int64_t>(127, (int64_t)u->pdf_first[(size_t)k] / 16);
         for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t)
-          tiles.push_back(t | (t + 1 == m->pdf_tile_off[p + 1] ? (int32_t)0x80000000 : 0));
+          tiles.push_back(t | (ef << 22) | (t + 1 == m->pdf_tile_off[p + 1] ? (int32_t)0x80000000 : 0));
       }
       toff[(size_t)i + 1] = (int64_t)tiles.size();
     }
@@ -579,11 +620,14 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     u->tiles_pto = m->pdf_tile_off;
+    u->tiles_reach = (int)reachable_only;
   }
   K1Args a;
   a.feats = u->feats_d; a.frame_off = u->frame_off_d; a.chunks = u->chunks_d; a.wimg = m->wimg_d;
   a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d; a.D = m->D;
+  a.interleave = reachable_only ? 1 : 0;
+  if (const char* e = getenv("KHG_K1_INTERLEAVE")) a.interleave = atoi(e);
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
@@ -595,6 +639,14 @@ extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   u->ll_valid = true;
   return KHG_OK;
 }
+extern "C" int khg_utts_pdf_first(const khg_utts* u, int32_t* first) {
+  if (!u || !first) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (u->pdf_first.size() != u->pdfs.size()) std::fill(first, first + u->pdfs.size(), 0);
+  else std::copy(u->pdf_first.begin(), u->pdf_first.end(), first);
+  return KHG_OK;
+}
+extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, false); }
+extern "C" int khg_loglikes_reachable(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, true); }
 extern "C" int khg_loglikes_layout(const khg_utts* u, int64_t* ll_off, int64_t* total) {
   if (!u) return khg_set_error(KHG_E_ARG, "bad arguments");
   if (ll_off) std::copy(u->ll_off.begin(), u->ll_off.end(), ll_off);
@@ -866,7 +918,10 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
       const size_t lds = sizeof(float) * ((size_t)K3_CHUNK * 4 * m->KQ + 5 * K3_CHUNK);
-      const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(32, (avg_chunks + 7) / 8));
+      // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
+      // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
+      int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
+      if (const char* e = getenv("KHG_K3_NY")) ny = std::max(1, atoi(e));
       KernelTimer kt(ctx, "k3_accumulate");
       if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
       else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);

@@ -169,8 +169,17 @@ class UtteranceSet:
         check(lib.khg_utts_pdfs(self.h, ptr(pdfs, C.c_int32)))
         return off, pdfs[: int(off[-1])]
 
-    def loglikes(self, model: DeviceModel):
-        check(lib.khg_loglikes(self.ctx.h, model.h, self.h))
+    def pdf_first_frames(self):
+        """Per listed pdf: first frame a decoder token can read it at (khg_utts_pdf_first)."""
+        off, _ = self.pdf_lists()
+        first = np.zeros(max(int(off[-1]), 1), np.int32)
+        check(lib.khg_utts_pdf_first(self.h, ptr(first, C.c_int32)))
+        return first[: int(off[-1])]
+
+    def loglikes(self, model: DeviceModel, reachable_only: bool = False):
+        """K1.  reachable_only: skip the (pdf, frame) cells no decoder token can read (khg_loglikes_reachable);
+        those cells of the score buffer are then unspecified."""
+        check((lib.khg_loglikes_reachable if reachable_only else lib.khg_loglikes)(self.ctx.h, model.h, self.h))
 
     def loglikes_layout(self):
         off = np.zeros(self.n_utt + 1, np.int64)

@@ -165,3 +165,62 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged):
     scale = np.abs(oa.mean_acc).max()
     np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * scale)
     np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
+
+
+def _first_frames(g, u, id2pdf, pdfs):
+    """Fewest emitting arcs before an arc with each listed pdf can be taken (0-1 BFS from the start state)."""
+    from collections import deque
+    s0, s1 = int(g["state_off"][u]), int(g["state_off"][u + 1])
+    S = s1 - s0
+    ao = g["arc_off"]
+    dmin = [None] * S
+    st = int(g["start"][u])
+    dmin[st] = 0
+    q = deque([st])
+    while q:
+        s = q.popleft()
+        for a in range(int(ao[s0 + s]), int(ao[s0 + s + 1])):
+            d, w = int(g["nextstate"][a]), 1 if g["ilabel"][a] >= 1 else 0
+            if dmin[d] is None or dmin[s] + w < dmin[d]:
+                dmin[d] = dmin[s] + w
+                (q.append if w else q.appendleft)(d)
+    first = {int(p): 10**9 for p in pdfs}
+    for s in range(S):
+        if dmin[s] is None:
+            continue
+        for a in range(int(ao[s0 + s]), int(ao[s0 + s + 1])):
+            if g["ilabel"][a] >= 1:
+                p = int(id2pdf[g["ilabel"][a]])
+                first[p] = min(first[p], dmin[s])
+    return first
+
+
+def test_reachable_only_loglikes_skip_only_unreadable_cells(ctx):
+    """khg_loglikes_reachable: every cell a decoder token can read is bit-identical to the full matrix, whole
+    16-frame tiles before a pdf's first readable frame are left untouched, and the alignment is unchanged."""
+    m, gc, om, ut, cost = build(150, 64, 40, n_utt=10, seed=77, min_phones=12, max_phones=40)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    full = us.download_loglikes()
+    res_full = us.align(tm, beam=200.0, retry_beam=0.0, acoustic_scale=0.1)
+    poff, pdfs = us.pdf_lists()
+    POISON = np.float32(12345.0)
+    us.upload_loglikes([np.full_like(f, POISON) for f in full])
+    us.loglikes(dm, reachable_only=True)
+    part = us.download_loglikes()
+    skipped = 0
+    for u in range(us.n_utt):
+        pl = pdfs[poff[u]: poff[u + 1]]
+        first = _first_frames(ut.graphs, u, m.id2pdf, pl)
+        for j, p in enumerate(pl):
+            t0 = 16 * (min(first[int(p)], 10**6) // 16)
+            assert np.array_equal(part[u][j, t0:], full[u][j, t0:]), (u, j)
+            untouched = part[u][j, :t0] == POISON
+            assert (untouched | (part[u][j, :t0] == full[u][j, :t0])).all()     # skipped, or computed exactly
+            skipped += int(untouched.sum())
+    total = sum(f.size for f in full)
+    assert skipped > 0.03 * total, (skipped, total)                              # the early triangle really is skipped
+    res = us.align(tm, beam=200.0, retry_beam=0.0, acoustic_scale=0.1)
+    assert np.array_equal(res["ali"], res_full["ali"]) and np.array_equal(res["status"], res_full["status"])
+    np.testing.assert_array_equal(res["like"], res_full["like"])
+    print("skipped fraction", skipped / total)
