@@ -917,7 +917,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     const bool use_mfma = maxG <= 128 && getenv("KHG_K3_VALU") == nullptr;
     if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
-      const size_t lds = sizeof(float) * ((size_t)K3_CHUNK * 4 * m->KQ + 5 * K3_CHUNK);
+      const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions
       // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
       // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
