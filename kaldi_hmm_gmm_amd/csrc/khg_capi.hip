@@ -18,6 +18,7 @@
 #include "../../include/khg_hip.h"
 
 #include "khg_k1_loglikes.hip.inc"
+#include "khg_k1_pdfmajor.hip.inc"
 #include "khg_k2_viterbi.hip.inc"
 #include "khg_k3_accstats.hip.inc"
 
@@ -325,6 +326,9 @@ struct khg_utts {
   int tiles_reach = -1;            // whether the walk lists carry those first frames (reachable-only K1) or zeros
   std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
   float* ll_d = nullptr; int64_t ll_total = 0; bool ll_valid = false;
+  // K1, pdf-major form: repacked features (once), work plan (per reachable flag)
+  float* xpl_d = nullptr; int64_t* utt_xtile_off_d = nullptr; int32_t xpl_kq = 0;
+  K1pEntry* p_ents_d = nullptr; K1pSlice* p_slices_d = nullptr; int32_t p_nslices = 0; int p_reach = -1; int32_t p_P = -1;
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
@@ -511,6 +515,7 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   plan_ll(u);
   DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d);
   DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear(); u->tiles_reach = -1;
+  DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d); u->p_reach = -1;
   u->ll_valid = false;
   return KHG_OK;
 }
@@ -522,6 +527,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->pdfs_d); DEVFREE(u->start_d); DEVFREE(u->in_off_d); DEVFREE(u->out_off_d);
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
+  DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
@@ -558,6 +564,99 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
 // 16-frame tiles per wave: 6 x 20 B-operand VGPRs fit 2 waves/SIMD at D <= 40 (KHG_K1_NF=5 selects the smaller chunk)
 static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); return KQ != 10 ? 5 : (e && atoi(e) == 5) ? 5 : 6; }
 
+// K1 in pdf-major form: plan (entries grouped by pdf, cut into workgroup slices) + repacked features.
+static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
+  int rc = KHG_OK;
+  const int KH = 2 * m->KQ;
+  if (!u->xpl_d || u->xpl_kq != m->KQ) {
+    // x tiles: ceil(T/16) per utterance, parity planes [2][16][KH] each
+    DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d);
+    std::vector<int64_t> xoff((size_t)u->n_utt + 1, 0);
+    for (int i = 0; i < u->n_utt; ++i) xoff[(size_t)i + 1] = xoff[(size_t)i] + (u->frame_off[i + 1] - u->frame_off[i] + 15) / 16;
+    const int64_t nx = xoff[(size_t)u->n_utt];
+    std::vector<int32_t> xutt((size_t)nx);
+    for (int i = 0; i < u->n_utt; ++i)
+      for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
+    int32_t* xutt_d = nullptr;
+    rc = dev_upload(ctx, &u->utt_xtile_off_d, xoff);
+    if (!rc) rc = dev_upload(ctx, &xutt_d, xutt);
+    if (!rc) rc = dev_alloc(&u->xpl_d, (size_t)std::max<int64_t>(nx, 1) * 2 * 16 * KH);
+    if (!rc && nx > 0) {
+      const int gb = (int)std::min<int64_t>(65535, (nx * (2 * 16 * KH / 4) + 255) / 256);
+      if (m->KQ == 10) hipLaunchKernelGGL(k1p_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
+      else hipLaunchKernelGGL(k1p_pack_x<20>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    }
+    DEVFREE(xutt_d);
+    if (rc) return rc;
+    u->xpl_kq = m->KQ;
+  }
+  if (!u->p_ents_d || u->p_reach != (int)reachable_only || u->p_P != m->P) {
+    DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
+    // entries grouped by pdf (counting sort keeps utterance order inside a pdf)
+    std::vector<int64_t> cnt((size_t)m->P + 1, 0);
+    for (int32_t p : u->pdfs) cnt[(size_t)p + 1]++;
+    for (int p = 0; p < m->P; ++p) cnt[(size_t)p + 1] += cnt[(size_t)p];
+    std::vector<K1pEntry> ents(u->pdfs.size());
+    std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+    for (int i = 0; i < u->n_utt; ++i) {
+      const int n16 = (int)((u->frame_off[i + 1] - u->frame_off[i] + 15) / 16);
+      for (int64_t k = u->pdf_off[i]; k < u->pdf_off[i + 1]; ++k) {
+        int ef = 0;
+        if (reachable_only) ef = (int)std::min<int64_t>(n16, (int64_t)u->pdf_first[(size_t)k] / 16);
+        ents[(size_t)cur[(size_t)u->pdfs[(size_t)k]]++] = K1pEntry{i, (int32_t)(k - u->pdf_off[i]), ef, n16 - ef};
+      }
+    }
+    // slices: <= TS tiles and <= K1P_MAXENT entries of one pdf each
+    const int TS = 1024;
+    std::vector<K1pSlice> slices;
+    for (int p = 0; p < m->P; ++p) {
+      int64_t e = cnt[(size_t)p];
+      const int64_t e_end = cnt[(size_t)p + 1];
+      int off = 0;                             // tiles of entry e already given out
+      while (e < e_end) {
+        while (e < e_end && ents[(size_t)e].nt - off <= 0) { ++e; off = 0; }
+        if (e >= e_end) break;
+        K1pSlice s{p, (int32_t)e, 0, off, 0};
+        int64_t ee = e;
+        int o = off;
+        while (ee < e_end && s.ntiles < TS && s.nent < K1P_MAXENT) {
+          const int avail = ents[(size_t)ee].nt - o;
+          if (avail <= 0) { ++s.nent; ++ee; o = 0; continue; }
+          const int take = std::min(avail, TS - s.ntiles);
+          s.ntiles += take;
+          ++s.nent;
+          if (take == avail) { ++ee; o = 0; } else { o += take; break; }
+        }
+        if (s.ntiles > 0) slices.push_back(s);
+        e = ee; off = o;
+      }
+    }
+    if (ents.size() >= (size_t)INT32_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: too many (utterance, pdf) entries");
+    rc = dev_upload(ctx, &u->p_ents_d, ents);
+    if (!rc) rc = dev_upload(ctx, &u->p_slices_d, slices);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u->p_nslices = (int32_t)slices.size();
+    u->p_reach = (int)reachable_only;
+    u->p_P = m->P;
+  }
+  K1pArgs a;
+  a.xpl = u->xpl_d; a.utt_xtile_off = u->utt_xtile_off_d; a.frame_off = u->frame_off_d;
+  a.ents = u->p_ents_d; a.slices = u->p_slices_d; a.wimg = m->wimg_d; a.pdf_tile_off = m->pdf_tile_off_d;
+  a.gauss_off = m->gauss_off_d; a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
+  if (u->p_nslices > 0) {
+    KernelTimer kt(ctx, "k1_loglikes");
+    if (m->KQ == 10) hipLaunchKernelGGL((k1p_loglikes<10, 2>), dim3(u->p_nslices), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k1p_loglikes<20, 1>), dim3(u->p_nslices), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  u->ll_valid = true;
+  return KHG_OK;
+}
+
 static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
   if (u->pdf_first.size() != u->pdfs.size()) reachable_only = false;
@@ -572,6 +671,14 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     if (!rc) rc = dev_upload(ctx, &u->ll_off_d, u->ll_off);
     if (!rc) rc = dev_alloc(&u->ll_d, (size_t)u->ll_total);
     if (rc) return rc;
+  }
+  {
+    // ---- pdf-major K1 (khg_k1_pdfmajor.hip.inc): pdfs of <= 64 Gaussians ----
+    int maxG = 0;
+    for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
+    const char* env = getenv("KHG_K1");
+    const bool want = env ? (strcmp(env, "pdf") == 0) : true;
+    if (want && maxG <= 64 && u->N > 0 && !u->pdfs.empty()) return loglikes_pdf_major(ctx, m, u, reachable_only);
   }
   if (!u->chunks_d || u->chunk_kq != m->KQ * 16 + k1_nf(m->KQ)) {
     DEVFREE(u->chunks_d);
