@@ -610,7 +610,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
       }
     }
     // slices: <= TS tiles and <= K1P_MAXENT entries of one pdf each
-    const int TS = 1024;
+    const int TS = getenv("KHG_K1P_TS") ? atoi(getenv("KHG_K1P_TS")) : 1024;
     std::vector<K1pSlice> slices;
     for (int p = 0; p < m->P; ++p) {
       int64_t e = cnt[(size_t)p];
@@ -640,6 +640,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     u->p_nslices = (int32_t)slices.size();
+    if (getenv("KHG_DEBUG")) { long long tt = 0; for (auto& s : slices) tt += s.ntiles; fprintf(stderr, "[khg] pdf-major plan: %zu entries, %zu slices, %lld tiles\n", ents.size(), slices.size(), tt); }
     u->p_reach = (int)reachable_only;
     u->p_P = m->P;
   }
