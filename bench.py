@@ -46,7 +46,7 @@ def pmc_traffic(frames_per_launch):
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as fh:
             pm = json.load(fh)
-        k1 = next(v for k, v in pm["kernels"].items() if k.startswith("k1_loglikes"))
+        k1 = next(v for k, v in pm["kernels"].items() if k.startswith(("k1p_loglikes", "k1_loglikes")))
         if abs(pm["frames_per_launch"] / frames_per_launch - 1.0) > 0.02:
             return None, None
         return k1["traffic_bytes"], "profiles/r1_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same launch size)"
@@ -190,14 +190,13 @@ def main():
     frames_local = int(ut.frame_off[-1])
     k1_flops = float((T * npdf).sum()) * (4.0 * D * G + 5.0 * G)  # alignment log-likes
     # cells K1 leaves out with khg_loglikes_reachable: whole 16-frame tiles before a pdf's first readable frame
-    # (at most the first 2 tiles of each wave = 8 tiles are dropped by the compiled variants) -- an estimate
     skipped_cells = 0.0
     if not args.full_loglikes:
         for s_ in sets:
             poff_, _ = s_.pdf_lists()
             first = s_.pdf_first_frames().astype(np.int64)
             Tu = np.repeat(np.diff(s_.frame_off), np.diff(poff_))
-            skipped_cells += float(np.minimum(16 * np.minimum(first // 16, 8), Tu).sum())
+            skipped_cells += float(np.minimum(16 * (first // 16), Tu).sum())
     k1_exec_frac = 1.0 - skipped_cells / max(float((T * npdf).sum()), 1.0)
     kernel_ms = {}
     ev_a = torch.cuda.Event()
@@ -295,7 +294,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "executed_cell_fraction": k1_exec_frac,
                          "note": "achieved/frac use the dense T x P_u contract FLOPs of SURVEY 8(d); K1 evaluates only the "
-                                 "(frame, pdf) cells a decoder token can read (executed_cell_fraction of them, estimate); "
+                                 "(frame, pdf) cells a decoder token can read, in whole 16-frame tiles (executed_cell_fraction of them); "
                                  "executed TFLOP/s = achieved x executed_cell_fraction",
                          "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},

@@ -53,8 +53,15 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
+@pytest.fixture(params=["pdf", "utt"])
+def k1_form(request, monkeypatch):
+    """Both K1 forms: pdf-major (default for <= 64 Gaussians per pdf) and utterance-major (KHG_K1=utt)."""
+    monkeypatch.setenv("KHG_K1", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("G,D", [(64, 40), (20, 13), (40, 80)])
-def test_loglikes_long_utterances(ctx, G, D):
+def test_loglikes_long_utterances(ctx, G, D, k1_form):
     """Utterance lengths that give a wave 0..NF frame tiles, uneven remainders, partial last tiles
     and more than one chunk per utterance (features-only set, one shared pdf list)."""
     from kaldi_hmm_gmm_amd import DeviceModel, UtteranceSet
@@ -82,7 +89,7 @@ def test_loglikes_long_utterances(ctx, G, D):
     us.close()
 
 
-def test_loglikes_fma_order_bitwise_gemm(ctx):
+def test_loglikes_fma_order_bitwise_gemm(ctx, k1_form):
     """The MFMA contraction is bit-for-bit the k-ordered fmaf chain the oracle restates; only
     exp/log differ, so with G == 1 (log-sum-exp of one term == that term) results are bit-equal."""
     m, gc, om, ut, cost = build(30, 1, 40, n_utt=3, seed=5)
@@ -195,7 +202,7 @@ def _first_frames(g, u, id2pdf, pdfs):
     return first
 
 
-def test_reachable_only_loglikes_skip_only_unreadable_cells(ctx):
+def test_reachable_only_loglikes_skip_only_unreadable_cells(ctx, k1_form):
     """khg_loglikes_reachable: every cell a decoder token can read is bit-identical to the full matrix, whole
     16-frame tiles before a pdf's first readable frame are left untouched, and the alignment is unchanged."""
     m, gc, om, ut, cost = build(150, 64, 40, n_utt=10, seed=77, min_phones=12, max_phones=40)
