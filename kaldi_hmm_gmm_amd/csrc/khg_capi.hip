@@ -329,6 +329,8 @@ struct khg_utts {
   // K1, pdf-major form: repacked features (once), work plan (per reachable flag)
   float* xpl_d = nullptr; int64_t* utt_xtile_off_d = nullptr; int32_t xpl_kq = 0;
   K1pEntry* p_ents_d = nullptr; K1pSlice* p_slices_d = nullptr; int32_t p_nslices = 0; int p_reach = -1; int32_t p_P = -1;
+  int32_t p_grp[6] = {0, 0, 0, 0, 0, 0};   // slices per block count (index 1..4); the plan also depends on the model's gauss_off
+  std::vector<int32_t> p_goff;
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
@@ -593,7 +595,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     if (rc) return rc;
     u->xpl_kq = m->KQ;
   }
-  if (!u->p_ents_d || u->p_reach != (int)reachable_only || u->p_P != m->P) {
+  if (!u->p_ents_d || u->p_reach != (int)reachable_only || u->p_P != m->P || u->p_goff != m->gauss_off) {
     DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
     // entries grouped by pdf (counting sort keeps utterance order inside a pdf)
     std::vector<int64_t> cnt((size_t)m->P + 1, 0);
@@ -634,6 +636,11 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
         e = ee; off = o;
       }
     }
+    // group the slices by the pdf's number of 16-Gaussian blocks: one launch (kernel instantiation) per count
+    auto nblk_of = [&](const K1pSlice& s) { return (m->gauss_off[s.pdf + 1] - m->gauss_off[s.pdf] + 15) / 16; };
+    std::stable_sort(slices.begin(), slices.end(), [&](const K1pSlice& x, const K1pSlice& y) { return nblk_of(x) < nblk_of(y); });
+    for (int k = 0; k <= 5; ++k) u->p_grp[k] = 0;
+    for (const auto& s : slices) u->p_grp[nblk_of(s)]++;          // counts per block count 1..4
     if (ents.size() >= (size_t)INT32_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: too many (utterance, pdf) entries");
     rc = dev_upload(ctx, &u->p_ents_d, ents);
     if (!rc) rc = dev_upload(ctx, &u->p_slices_d, slices);
@@ -643,6 +650,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     if (getenv("KHG_DEBUG")) { long long tt = 0; for (auto& s : slices) tt += s.ntiles; fprintf(stderr, "[khg] pdf-major plan: %zu entries, %zu slices, %lld tiles\n", ents.size(), slices.size(), tt); }
     u->p_reach = (int)reachable_only;
     u->p_P = m->P;
+    u->p_goff = m->gauss_off;
   }
   K1pArgs a;
   a.xpl = u->xpl_d; a.utt_xtile_off = u->utt_xtile_off_d; a.frame_off = u->frame_off_d;
@@ -650,8 +658,17 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
   a.gauss_off = m->gauss_off_d; a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
   if (u->p_nslices > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
-    if (m->KQ == 10) hipLaunchKernelGGL((k1p_loglikes<10, 2>), dim3(u->p_nslices), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k1p_loglikes<20, 1>), dim3(u->p_nslices), dim3(256), 0, ctx->stream, a);
+    int first = 0;
+    for (int nb = 1; nb <= 4; ++nb) {
+      const int n = u->p_grp[nb];
+      if (n == 0) continue;
+      a.slice0 = first;
+      first += n;
+#define K1P_LAUNCH(KQ_, NB_, WPS_) hipLaunchKernelGGL((k1p_loglikes<KQ_, NB_, WPS_>), dim3(n), dim3(256), 0, ctx->stream, a)
+      if (m->KQ == 10) { if (nb == 1) K1P_LAUNCH(10, 1, 2); else if (nb == 2) K1P_LAUNCH(10, 2, 2); else if (nb == 3) K1P_LAUNCH(10, 3, 2); else K1P_LAUNCH(10, 4, 2); }
+      else { if (nb == 1) K1P_LAUNCH(20, 1, 1); else if (nb == 2) K1P_LAUNCH(20, 2, 1); else if (nb == 3) K1P_LAUNCH(20, 3, 1); else K1P_LAUNCH(20, 4, 1); }
+#undef K1P_LAUNCH
+    }
     HIPCHK(hipGetLastError());
   }
   u->ll_valid = true;
