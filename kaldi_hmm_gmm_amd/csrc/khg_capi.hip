@@ -329,7 +329,7 @@ struct khg_utts {
   // K1, pdf-major form: repacked features (once), work plan (per reachable flag)
   float* xpl_d = nullptr; int64_t* utt_xtile_off_d = nullptr; int32_t xpl_kq = 0;
   K1pEntry* p_ents_d = nullptr; K1pSlice* p_slices_d = nullptr; int32_t p_nslices = 0; int p_reach = -1; int32_t p_P = -1;
-  int32_t p_grp[6] = {0, 0, 0, 0, 0, 0};   // slices per block count (index 1..4); the plan also depends on the model's gauss_off
+  int32_t p_grp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // slices per block count (index 1..8); the plan also depends on the model's gauss_off
   std::vector<int32_t> p_goff;
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
@@ -639,7 +639,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     // group the slices by the pdf's number of 16-Gaussian blocks: one launch (kernel instantiation) per count
     auto nblk_of = [&](const K1pSlice& s) { return (m->gauss_off[s.pdf + 1] - m->gauss_off[s.pdf] + 15) / 16; };
     std::stable_sort(slices.begin(), slices.end(), [&](const K1pSlice& x, const K1pSlice& y) { return nblk_of(x) < nblk_of(y); });
-    for (int k = 0; k <= 5; ++k) u->p_grp[k] = 0;
+    for (int k = 0; k < 10; ++k) u->p_grp[k] = 0;
     for (const auto& s : slices) u->p_grp[nblk_of(s)]++;          // counts per block count 1..4
     if (ents.size() >= (size_t)INT32_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: too many (utterance, pdf) entries");
     rc = dev_upload(ctx, &u->p_ents_d, ents);
@@ -659,14 +659,19 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
   if (u->p_nslices > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
     int first = 0;
-    for (int nb = 1; nb <= 4; ++nb) {
+    for (int nb = 1; nb <= 8; ++nb) {
       const int n = u->p_grp[nb];
       if (n == 0) continue;
       a.slice0 = first;
       first += n;
 #define K1P_LAUNCH(KQ_, NB_, WPS_) hipLaunchKernelGGL((k1p_loglikes<KQ_, NB_, WPS_>), dim3(n), dim3(256), 0, ctx->stream, a)
-      if (m->KQ == 10) { if (nb == 1) K1P_LAUNCH(10, 1, 2); else if (nb == 2) K1P_LAUNCH(10, 2, 2); else if (nb == 3) K1P_LAUNCH(10, 3, 2); else K1P_LAUNCH(10, 4, 2); }
-      else { if (nb == 1) K1P_LAUNCH(20, 1, 1); else if (nb == 2) K1P_LAUNCH(20, 2, 1); else if (nb == 3) K1P_LAUNCH(20, 3, 1); else K1P_LAUNCH(20, 4, 1); }
+      if (m->KQ == 10) {
+        switch (nb) { case 1: K1P_LAUNCH(10, 1, 2); break; case 2: K1P_LAUNCH(10, 2, 2); break; case 3: K1P_LAUNCH(10, 3, 2); break; case 4: K1P_LAUNCH(10, 4, 2); break;
+                      case 5: K1P_LAUNCH(10, 5, 2); break; case 6: K1P_LAUNCH(10, 6, 2); break; case 7: K1P_LAUNCH(10, 7, 2); break; default: K1P_LAUNCH(10, 8, 2); break; }
+      } else {
+        switch (nb) { case 1: K1P_LAUNCH(20, 1, 1); break; case 2: K1P_LAUNCH(20, 2, 1); break; case 3: K1P_LAUNCH(20, 3, 1); break; case 4: K1P_LAUNCH(20, 4, 1); break;
+                      case 5: K1P_LAUNCH(20, 5, 1); break; case 6: K1P_LAUNCH(20, 6, 1); break; case 7: K1P_LAUNCH(20, 7, 1); break; default: K1P_LAUNCH(20, 8, 1); break; }
+      }
 #undef K1P_LAUNCH
     }
     HIPCHK(hipGetLastError());
@@ -691,12 +696,12 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     if (rc) return rc;
   }
   {
-    // ---- pdf-major K1 (khg_k1_pdfmajor.hip.inc): pdfs of <= 64 Gaussians ----
+    // ---- pdf-major K1 (khg_k1_pdfmajor.hip.inc): pdfs of <= 128 Gaussians ----
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const char* env = getenv("KHG_K1");
     const bool want = env ? (strcmp(env, "pdf") == 0) : true;
-    if (want && maxG <= 64 && u->N > 0 && !u->pdfs.empty()) return loglikes_pdf_major(ctx, m, u, reachable_only);
+    if (want && maxG <= 128 && u->N > 0 && !u->pdfs.empty()) return loglikes_pdf_major(ctx, m, u, reachable_only);
   }
   if (!u->chunks_d || u->chunk_kq != m->KQ * 16 + k1_nf(m->KQ)) {
     DEVFREE(u->chunks_d);
