@@ -310,7 +310,7 @@ struct khg_utts {
   bool has_graphs = false;
   std::vector<int64_t> frame_off, state_off, pdf_off, ll_off, bp_off, path_off, words_off;
   std::vector<int32_t> pdfs;
-  int32_t max_states = 0, max_inarcs = 0, max_indeg = 0;
+  int32_t max_states = 0, max_inarcs = 0, max_indeg = 0, max_outdeg = 0;
   bool has_eps = false;
   // device
   const float* feats_d = nullptr; bool own_feats = false;
@@ -406,6 +406,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
       if (S > 65535) return fail(KHG_E_UNSUPPORTED, "khg_utts_create: more than 65535 states in one decoding graph");
       u->max_states = std::max<int64_t>(u->max_states, S);
       u->max_inarcs = std::max<int64_t>(u->max_inarcs, A);
+      for (int64_t s = 0; s < S; ++s) u->max_outdeg = std::max<int32_t>(u->max_outdeg, (int32_t)(arc_off[s0 + s + 1] - arc_off[s0 + s]));
       // pdf list of this utterance = distinct id2pdf[ilabel] over its arcs
       tmp_pdfs.clear();
       int64_t nwords = 0;
@@ -906,7 +907,17 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   HIPCHK(hipStreamWaitEvent(side, u->ev_dp, 0));
   {
     KernelTimer kt(ctx, "k2_viterbi_faithful", side);
-    hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, side, a);
+    // wave-parallel form for the common training graphs (no epsilon-input arcs, <= 1000 states, out-degree <= 8);
+    // the one-lane form handles everything else
+    const int odeg = std::max(1, (int)u->max_outdeg);
+    const size_t lds_w = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 8 * (S + 1) + 5 * 4 * A + 8 * ((S * odeg + 63) / 64 + 2) + A + 64;
+    const bool wave_ok = !u->has_eps && S <= 1000 && odeg <= 8 && lds_w <= 160 * 1024 && getenv("KHG_K2_SERIAL") == nullptr;
+    if (wave_ok) {
+      if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+      hipLaunchKernelGGL(k2_viterbi_faithful_wave, dim3(u->n_utt), dim3(64), lds_w, side, a, odeg);
+    } else {
+      hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, side, a);
+    }
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(u->ev_ali, side));

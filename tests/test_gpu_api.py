@@ -352,3 +352,36 @@ def test_faster_decoder_class_like_reference_binding(khg):
     assert not dec.reached_final() and dec.get_best_path()[0] is False
     with pytest.raises(khg.KhgError):
         khg.FasterDecoder(fst, khg.FasterDecoderOptions(max_active=1))
+
+
+def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, monkeypatch):
+    """The wave-parallel order-faithful decoder (prefix-min pruning, atomic per-state minima, first-insertion
+    list order) against the one-lane emulation and the oracle's FasterDecoder, on scores that make the beam
+    really prune, for the GetCutoff branches (default, max_active, min_active = 0)."""
+    m, gc, om, ut, cost = build(120, 2, 10, n_utt=40, seed=33, min_phones=8, max_phones=30)
+    dm, tm, us = _dev(ctx, m, gc, ut, cost)
+    poff, pdfs = us.pdf_lists()
+    rng = np.random.default_rng(5)
+    mats = [(-6 * rng.random((poff[u + 1] - poff[u], int(ut.frame_off[u + 1] - ut.frame_off[u])))).astype(np.float32)
+            for u in range(us.n_utt)]
+    us.upload_loglikes(mats)
+    seen = 0
+    for kw in (dict(beam=1.5, retry_beam=6.0), dict(beam=3.0, retry_beam=0.0, max_active=12, min_active=3),
+               dict(beam=2.0, retry_beam=8.0, min_active=0), dict(beam=4.0, retry_beam=0.0, max_active=40, min_active=20, beam_delta=0.25)):
+        monkeypatch.delenv("KHG_K2_SERIAL", raising=False)
+        rw = us.align(tm, acoustic_scale=1.0, **kw)
+        monkeypatch.setenv("KHG_K2_SERIAL", "1")
+        rs = us.align(tm, acoustic_scale=1.0, **kw)
+        assert np.array_equal(rw["status"], rs["status"]), kw
+        assert np.array_equal(rw["ali"], rs["ali"]), kw
+        np.testing.assert_array_equal(rw["like"], rs["like"])
+        seen += int(((rw["status"] & 8) != 0).sum())
+        for u in range(0, us.n_utt, 5):
+            T = int(ut.frame_off[u + 1] - ut.frame_off[u])
+            want = orc.align_utterance_ll(oracle_graph(ut, u, cost), m.id2pdf, T, pdfs[poff[u]: poff[u + 1]], mats[u],
+                                          acoustic_scale=1.0, **kw)
+            assert (int(rw["status"][u]) & 3) == (want["status"] & 3), (kw, u)
+            a = rw["ali"][ut.frame_off[u]: ut.frame_off[u + 1]]
+            if not (want["status"] & 1):
+                assert (a == want["ali"]).all(), (kw, u)
+    assert seen > 20, "the fallback decoder was hardly exercised"
