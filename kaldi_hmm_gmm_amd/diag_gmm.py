@@ -237,6 +237,43 @@ class DiagGmm:
         self._means_invvars = (self._means_invvars + rv * f32(perturb_factor)).astype(f32)
         self.compute_gconsts()
 
+    def generate(self, randn=None) -> np.ndarray:   # csrc/diag-gmm.cc:410-446
+        """One sample.  Like the reference, the component is picked with `tot * Randn() * 0.99999` -- a NORMAL
+        deviate, not a uniform one (so component 0 is chosen for every non-positive draw)."""
+        rng = randn or (lambda shape: np.random.standard_normal(shape).astype(f32))
+        tot = f32(self._weights.sum())
+        if not tot > 0.0:
+            raise KhgError("tot > 0.0 assertion failed")
+        r = float(tot) * float(np.asarray(rng(1)).reshape(-1)[0]) * 0.99999
+        i, acc, n = 0, 0.0, self.num_gauss
+        while i < n and acc + float(self._weights[i]) < r:
+            acc += float(self._weights[i])
+            i += 1
+        i = min(i, n - 1)
+        t = self._inv_vars[i]
+        return (self._means_invvars[i] / t + np.asarray(rng(self.dim), f32).reshape(-1) / np.sqrt(t)).astype(f32)
+
+    def interpolate(self, rho: float, source: "DiagGmm", flags=0x7):   # csrc/diag-gmm.cc:460-484 (flags default kGmmAll)
+        if self.num_gauss != source.num_gauss or self.dim != source.dim:
+            raise KhgError("NumGauss() == source.NumGauss() && Dim() == source.Dim() assertion failed")
+        flags = int(flags)
+        # DiagGmmNormal of both (double), csrc/diag-gmm-normal.cc:14-20
+        w = self._weights.astype(np.float64); wv = 1.0 / self._inv_vars.astype(np.float64); wm = self._means_invvars.astype(np.float64) * wv
+        tw = source._weights.astype(np.float64); tv = 1.0 / source._inv_vars.astype(np.float64); tmn = source._means_invvars.astype(np.float64) * tv
+        rho = float(f32(rho))
+        if flags & 0x4:
+            w = w * (1.0 - rho) + tw * rho
+            w = w / w.sum()
+        if flags & 0x1:
+            wm = wm * (1.0 - rho) + tmn * rho
+        if flags & 0x2:
+            wv = wv * (1.0 - rho) + tv * rho
+        # CopyToDiagGmm(kGmmAll) (csrc/diag-gmm-normal.cc:22-48)
+        self._weights = w.astype(f32)
+        self._inv_vars = (1.0 / wv).astype(f32)
+        self._means_invvars = (wm.astype(f32) * self._inv_vars).astype(f32)
+        self.compute_gconsts()
+
     # pickle: (weights, inv_vars, means_invvars); gconsts are re-derived (python/csrc/diag-gmm.cc:157-167)
     def __getstate__(self):
         return (self._weights, self._inv_vars, self._means_invvars)

@@ -282,3 +282,29 @@ def test_shard_utterances_balances_frames():
     assert sorted(np.concatenate(shards).tolist()) == list(range(1000))
     loads = [T[s].sum() for s in shards]
     assert max(loads) - min(loads) <= T.max()
+
+
+def test_diag_gmm_generate_and_interpolate():
+    """csrc/diag-gmm.cc:410-446 (Generate) and :460-484 (Interpolate) on the host object (no GPU work)."""
+    rng = np.random.default_rng(3)
+    g = khg.DiagGmm(nmix=3, dim=4)
+    g.set_weights(np.array([.2, .3, .5], np.float32)); g.set_means(rng.standard_normal((3, 4)).astype(np.float32))
+    g.set_invvars(np.full((3, 4), 2.0, np.float32)); g.compute_gconsts()
+    h = khg.DiagGmm(nmix=3, dim=4)
+    h.set_weights(np.array([.5, .3, .2], np.float32)); h.set_means(np.zeros((3, 4), np.float32))
+    h.set_invvars(np.ones((3, 4), np.float32)); h.compute_gconsts()
+    # a draw of exactly 0 picks component 0 and returns its mean
+    x = g.generate(randn=lambda shape: np.zeros(shape, np.float32))
+    assert x.dtype == np.float32 and np.allclose(x, g.means[0], atol=1e-6)
+    # a large positive draw runs off the end -> last component; unit deviates add one standard deviation
+    x = g.generate(randn=lambda shape: np.ones(shape, np.float32) * (5.0 if np.prod(shape) == 1 else 1.0))
+    assert np.allclose(x, g.means[2] + np.sqrt(0.5), atol=1e-5)
+    m0 = g.means.copy()
+    g.interpolate(0.25, h)
+    assert np.allclose(g.means, 0.75 * m0, atol=1e-6) and np.allclose(g.vars, 0.75 * 0.5 + 0.25)
+    assert np.allclose(g.weights, [0.275, 0.3, 0.425], atol=1e-6) and g.valid_gconsts
+    w0 = g.weights.copy()
+    g.interpolate(0.5, h, flags=khg.GmmUpdateFlags.kGmmMeans)
+    assert np.allclose(g.weights, w0) and np.allclose(g.means, 0.375 * m0, atol=1e-6)
+    with pytest.raises(khg.KhgError):
+        g.interpolate(0.5, khg.DiagGmm(nmix=2, dim=4))
