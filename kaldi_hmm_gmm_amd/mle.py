@@ -220,6 +220,37 @@ class AccumDiagGmm:
         if self._flags & 2:
             self.variance_accumulator += acc.variance_accumulator * s
 
+    def smooth_stats(self, tau: float):   # csrc/mle-diag-gmm.cc:192-203 (tau "virtual counts" of the acc's own stats)
+        tau = float(f32(tau))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sv = (self.occupancy + tau) / self.occupancy
+        if self.mean_accumulator.size:
+            self.mean_accumulator *= sv[:, None]
+        if self.variance_accumulator.size:
+            self.variance_accumulator *= sv[:, None]
+        self.occupancy = self.occupancy + tau
+
+    def smooth_with_accum(self, tau: float, src_acc: "AccumDiagGmm"):   # :209-226
+        if src_acc.num_gauss != self.num_gauss or src_acc.dim != self._dim:
+            raise KhgError("src_acc.NumGauss() == num_comp_ && src_acc.Dim() == dim_ assertion failed")
+        tau = float(f32(tau))
+        for i in range(self.num_gauss):
+            so = src_acc.occupancy[i]
+            if so != 0.0:    # can only smooth where the source saw data (the reference warns otherwise)
+                self.occupancy[i] += tau
+                self.mean_accumulator[i] += src_acc.mean_accumulator[i] * tau / so
+                self.variance_accumulator[i] += src_acc.variance_accumulator[i] * tau / so
+
+    def smooth_with_model(self, tau: float, gmm: DiagGmm):   # :228-241
+        if gmm.num_gauss != self.num_gauss or gmm.dim != self._dim:
+            raise KhgError("gmm.NumGauss() == num_comp_ && gmm.Dim() == dim_ assertion failed")
+        tau = float(f32(tau))
+        means = gmm.means.astype(f64)
+        vars_ = gmm.vars.astype(f64)
+        self.mean_accumulator += means * tau
+        self.variance_accumulator += (vars_ + means * means) * tau
+        self.occupancy = self.occupancy + tau
+
     def copy(self) -> "AccumDiagGmm":
         o = AccumDiagGmm()
         o._flags, o._dim = self._flags, self._dim
@@ -334,6 +365,16 @@ class AccumAmDiagGmm:
         self._total_log_like += float(f32(f32(ll) * f32(weight)))
         self._total_frames += float(f32(weight))
         return ll
+
+    def accumulate_for_gmm_two_feats(self, model: AmDiagGmm, data1, data2, gmm_index: int, weight: float) -> float:
+        """.cc:54-76: posteriors of data1 under the pdf, statistics of data2."""
+        self._chk(gmm_index)
+        ll, post = model.get_pdf(gmm_index).component_posteriors(data1)
+        w = f32(weight)
+        self._accs[gmm_index].accumulate_from_posteriors(data2, post * w)
+        self._total_log_like += float(f32(f32(ll) * w))
+        self._total_frames += float(w)
+        return float(f32(ll))
 
     def accumulate_from_posteriors(self, model: AmDiagGmm, data, gmm_index: int, posteriors):
         self._chk(gmm_index)

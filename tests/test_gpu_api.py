@@ -79,6 +79,25 @@ def test_accumulate_from_diag_like_reference_test(khg):
         assert np.allclose(acc.variance_accumulator, np.outer(post * weight, x * x), rtol=1e-5, atol=1e-7)
 
 
+def test_accumulate_for_gmm_two_feats(khg):
+    # csrc/mle-am-diag-gmm.cc:54-76: posteriors of data1, statistics of data2
+    rng = np.random.default_rng(8)
+    g, w, mean, var = _gmm(khg, rng, 6, 8)
+    am = khg.AmDiagGmm()
+    am.add_pdf(g)
+    x1, x2 = rng.random(8).astype(np.float32), rng.random(8).astype(np.float32)
+    ll0, post = g.component_posteriors(x1)
+    acc = khg.AccumAmDiagGmm()
+    acc.init(am, khg.GmmUpdateFlags.kGmmAll)
+    ll = acc.accumulate_for_gmm_two_feats(model=am, data1=x1, data2=x2, gmm_index=0, weight=0.5)
+    assert abs(ll - ll0) < 1e-5
+    a = acc.get_acc(0)
+    assert np.allclose(a.occupancy, post * 0.5, rtol=1e-6)
+    assert np.allclose(a.mean_accumulator, np.outer(post * 0.5, x2), rtol=1e-5, atol=1e-7)
+    assert np.allclose(a.variance_accumulator, np.outer(post * 0.5, x2 * x2), rtol=1e-5, atol=1e-7)
+    assert abs(acc.tot_count - 0.5) < 1e-7 and abs(acc.tot_log_like - 0.5 * ll0) < 1e-5
+
+
 def test_invalid_model_raises_like_reference(khg):
     # decodable-am-diag-gmm.cc:63-65 / diag-gmm.cc:160-162: NaN/Inf log-likelihood -> RuntimeError
     g = khg.DiagGmm(nmix=2, dim=3)

@@ -308,3 +308,36 @@ def test_diag_gmm_generate_and_interpolate():
     assert np.allclose(g.weights, w0) and np.allclose(g.means, 0.375 * m0, atol=1e-6)
     with pytest.raises(khg.KhgError):
         g.interpolate(0.5, khg.DiagGmm(nmix=2, dim=4))
+
+
+def test_accum_diag_gmm_smoothing():
+    # csrc/mle-diag-gmm.cc:192-241 (SmoothStats / SmoothWithAccum / SmoothWithModel)
+    rng = np.random.default_rng(11)
+    am = _rand_am(rng, 1, 3, 4)
+    g = am.get_pdf(0)
+    acc = khg.AccumDiagGmm(g, khg.GmmUpdateFlags.kGmmAll)
+    for _ in range(20):
+        acc.accumulate_from_posteriors(rng.standard_normal(4).astype(np.float32), rng.dirichlet(np.ones(3)).astype(np.float32))
+    occ, m, v = acc.occupancy.copy(), acc.mean_accumulator.copy(), acc.variance_accumulator.copy()
+    a = acc.copy()
+    a.smooth_stats(2.0)
+    assert np.allclose(a.occupancy, occ + 2.0)
+    # per-Gaussian means (mean_acc / occ) are unchanged by adding virtual counts of the acc's own stats
+    assert np.allclose(a.mean_accumulator / a.occupancy[:, None], m / occ[:, None])
+    assert np.allclose(a.variance_accumulator / a.occupancy[:, None], v / occ[:, None])
+    src = acc.copy()
+    src.scale(3.0, 7)
+    src.occupancy[1] = 0.0            # a source Gaussian without data is skipped
+    b = acc.copy()
+    b.smooth_with_accum(4.0, src)
+    assert np.allclose(b.occupancy, occ + np.array([4.0, 0.0, 4.0]))
+    assert np.allclose(b.mean_accumulator[0], m[0] + src.mean_accumulator[0] * 4.0 / src.occupancy[0])
+    assert np.array_equal(b.mean_accumulator[1], m[1]) and np.array_equal(b.variance_accumulator[1], v[1])
+    c = acc.copy()
+    c.smooth_with_model(1.5, g)
+    mu, var = g.means.astype(np.float64), g.vars.astype(np.float64)
+    assert np.allclose(c.occupancy, occ + 1.5)
+    assert np.allclose(c.mean_accumulator, m + 1.5 * mu)
+    assert np.allclose(c.variance_accumulator, v + 1.5 * (var + mu * mu))
+    with pytest.raises(khg.KhgError):
+        c.smooth_with_model(1.0, khg.DiagGmm(nmix=2, dim=4))
