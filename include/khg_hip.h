@@ -196,6 +196,31 @@ int khg_mle_am_diag_gmm_update(const khg_mle_options *o, int32_t num_pdfs, int32
                                float *count, int32_t *floored_elems, int32_t *floored_gauss,
                                int32_t *removed);
 
+/* ---- K4: the same M-step on the device ---------------------------------- */
+/* MleAmDiagGmmUpdate (csrc/mle-am-diag-gmm.cc:153-202; per pdf MleDiagGmmUpdate,
+ * csrc/mle-diag-gmm.cc:243-390, DiagGmmNormal csrc/diag-gmm-normal.cc:14-48, ComputeGconsts
+ * csrc/diag-gmm.cc:103-147, RemoveComponents :853-938) run on the (all-reduced) accumulators where K3
+ * left them: no 205 MB accumulator download, no host update, no parameter upload.  The model handle is
+ * updated IN PLACE (row-major parameters, the K1 tile image, gauss_off when Gaussians were removed --
+ * then call khg_accs_relayout before the next khg_acc_stats).  weights, inv_vars and means_invvars are
+ * bit-identical to khg_mle_am_diag_gmm_update; gconsts / objf_change go through logf and may differ from
+ * the host's in the last place.  The mixture weights (which khg_model_create does not take; K1-K3 only
+ * need gconsts) must have been set with khg_model_set_weights. */
+int khg_model_set_weights(khg_ctx *ctx, khg_model *m, const float *weights_h);
+int khg_model_mle_update(khg_ctx *ctx, khg_model *m, const khg_accs *a, const khg_mle_options *o,
+                         uint16_t flags, float *objf_change, float *count, int32_t *floored_elems,
+                         int32_t *floored_gauss, int32_t *removed);
+/* total Gaussians and (gauss_off_h may be NULL) the current gauss_off[num_pdfs+1] of the handle */
+int khg_model_num_gauss(const khg_model *m, int64_t *total, int32_t *gauss_off_h);
+/* parameters back to the host (AmDiagGmm::Write needs them); any pointer may be NULL */
+int khg_model_download(khg_ctx *ctx, const khg_model *m, float *weights_h, float *gconsts_h,
+                       float *means_invvars_h, float *inv_vars_h);
+/* re-lay the accumulator block for the handle's current gauss_off and zero it */
+int khg_accs_relayout(khg_ctx *ctx, khg_accs *a, const khg_model *m);
+/* only the transition statistics [num_tids+1] and the 8 scalars (what TransitionModel::MleUpdate and the
+ * log line of scripts/gmm_acc_stats_ali.py need) -- a few kB instead of the whole block */
+int khg_accs_download_trans(khg_ctx *ctx, const khg_accs *a, double *trans_h, double *scalars_h);
+
 /* TransitionModel::MleUpdate (csrc/transition-model.cc:657-750) + ComputeDerivedOfProbs (:339-359) */
 int khg_transition_mle_update(int32_t num_tstates, const int32_t *state2id,
                               const int32_t *self_loop_of, const double *stats, float floor_,

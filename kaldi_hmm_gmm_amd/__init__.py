@@ -15,7 +15,8 @@ from .diag_gmm import AmDiagGmm, DiagGmm  # noqa: F401
 from .fst import StdArc, StdVectorFst, modify_graph_for_careful_alignment  # noqa: F401
 from .hmm_topology import HmmState, HmmTopology  # noqa: F401
 from .mle import (AccumAmDiagGmm, AccumDiagGmm, GmmUpdateFlags, MleDiagGmmOptions, augment_gmm_flags,  # noqa: F401
-                  get_split_targets, gmm_flags_to_str, ml_objective, mle_am_diag_gmm_update, mle_diag_gmm_update,
+                  get_split_targets, gmm_flags_to_str, ml_objective, mle_am_diag_gmm_update,
+                  mle_am_diag_gmm_update_device, mle_diag_gmm_update,
                   str_to_gmm_flags)
 from .scripts import (gmm_acc_stats_ali, gmm_acc_stats_ali_batch, gmm_align_compiled, gmm_align_compiled_batch,  # noqa: F401
                       gmm_boost_silence, gmm_est, gmm_init_mono)

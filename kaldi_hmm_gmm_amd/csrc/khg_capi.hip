@@ -21,6 +21,7 @@
 #include "khg_k1_pdfmajor.hip.inc"
 #include "khg_k2_viterbi.hip.inc"
 #include "khg_k3_accstats.hip.inc"
+#include "khg_k4_mstep.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -197,7 +198,51 @@ struct khg_model {
   int32_t* pdf_tile_off_d = nullptr;
   int32_t* gauss_off_d = nullptr;
   float *gconsts_d = nullptr, *miv_d = nullptr, *iv_d = nullptr, *nhiv_d = nullptr;
+  float* weights_d = nullptr;   // only the device M-step needs them (khg_model_set_weights)
+  bool has_weights = false;
+  int32_t wimg_tiles = 0;       // tiles wimg_d was allocated for
 };
+
+// (Re)build everything derived from gauss_off + the row-major parameters in HBM: the tile offsets, the K1
+// tile image and the -0.5*inv_vars copy K3 reads -- packed ON THE DEVICE (k0_pack_tiles), no host-side
+// 113 MB image, no extra copies.  Used by khg_model_create and after the device M-step.
+static int model_pack(khg_ctx* ctx, khg_model* m) {
+  const int P = m->P, D = m->D;
+  m->pdf_tile_off.resize((size_t)P + 1);
+  int nt = 0;
+  for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (m->gauss_off[p + 1] - m->gauss_off[p] + 31) / 32; }
+  m->pdf_tile_off[P] = nt;
+  m->ntiles = nt;
+  const int TILE = khg_tile_floats(m->KQ);
+  if (!m->pdf_tile_off_d) { int rc = dev_alloc(&m->pdf_tile_off_d, (size_t)P + 1); if (rc) return rc; }
+  if (!m->gauss_off_d) { int rc = dev_alloc(&m->gauss_off_d, (size_t)P + 1); if (rc) return rc; }
+  HIPCHK(hipMemcpyAsync(m->pdf_tile_off_d, m->pdf_tile_off.data(), sizeof(int32_t) * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(m->gauss_off_d, m->gauss_off.data(), sizeof(int32_t) * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (!m->nhiv_d) { int rc = dev_alloc(&m->nhiv_d, (size_t)m->sumG * D); if (rc) return rc; }
+  if (!m->wimg_d || m->wimg_tiles < nt) {
+    DEVFREE(m->wimg_d);
+    int rc = dev_alloc(&m->wimg_d, (size_t)nt * TILE);
+    if (rc) return rc;
+    m->wimg_tiles = nt;
+  }
+  std::vector<int32_t> tile_pdf((size_t)nt);   // tile -> pdf map for the pack kernel
+  for (int p = 0; p < P; ++p)
+    for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
+  int32_t* tile_pdf_d = nullptr;
+  int rc = dev_upload(ctx, &tile_pdf_d, tile_pdf);
+  if (!rc) {
+    KernelTimer kt(ctx, "k0_pack_tiles");
+    if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+    else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+  }
+  if (!rc) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // tile_pdf and the host offset vectors are free after this
+    if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  }
+  DEVFREE(tile_pdf_d);
+  return rc;
+}
 
 extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_t* gauss_off,
                                 const float* gconsts, const float* miv, const float* iv, khg_model** out) {
@@ -212,44 +257,17 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
   m->KQ = (D <= 40) ? 10 : 20;
   m->gauss_off.assign(gauss_off, gauss_off + P + 1);
   m->sumG = gauss_off[P];
-  m->pdf_tile_off.resize(P + 1);
-  int nt = 0;
-  for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (gauss_off[p + 1] - gauss_off[p] + 31) / 32; }
-  m->pdf_tile_off[P] = nt;
-  m->ntiles = nt;
-  // The row-major parameters go up as they are (K3 reads them); the K1 tile image and the -0.5*inv_vars
-  // copy are packed from them ON THE DEVICE (k0_pack_tiles) -- no host-side 113 MB image, no extra copies.
-  const int TILE = khg_tile_floats(m->KQ);
-  int rc = dev_upload(ctx, &m->pdf_tile_off_d, m->pdf_tile_off);
-  if (!rc) rc = dev_upload(ctx, &m->gauss_off_d, m->gauss_off);
+  // the row-major parameters go up as they are (K3 and the device M-step read them)
   auto up = [&](float** dst, const float* src, size_t n) -> int {
     int r = dev_alloc(dst, n);
     if (r) return r;
     HIPCHK(hipMemcpyAsync(*dst, src, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
     return KHG_OK;
   };
-  if (!rc) rc = up(&m->gconsts_d, gconsts, (size_t)m->sumG);
+  int rc = up(&m->gconsts_d, gconsts, (size_t)m->sumG);
   if (!rc) rc = up(&m->miv_d, miv, (size_t)m->sumG * D);
   if (!rc) rc = up(&m->iv_d, iv, (size_t)m->sumG * D);
-  if (!rc) rc = dev_alloc(&m->nhiv_d, (size_t)m->sumG * D);
-  if (!rc) rc = dev_alloc(&m->wimg_d, (size_t)nt * TILE);
-  if (!rc) {
-    // tile -> pdf map for the pack kernel
-    std::vector<int32_t> tile_pdf((size_t)nt);
-    for (int p = 0; p < P; ++p)
-      for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
-    int32_t* tile_pdf_d = nullptr;
-    rc = dev_upload(ctx, &tile_pdf_d, tile_pdf);
-    if (!rc) {
-      if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
-      else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
-      hipError_t e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // tile_pdf (host) and the caller's arrays are free after this
-      if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
-    }
-    DEVFREE(tile_pdf_d);
-  }
-  if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
+  if (!rc) rc = model_pack(ctx, m);   // ends with a stream sync: the caller's arrays are free after this
   if (rc) { khg_model_destroy(m); return rc; }
   *out = m;
   return KHG_OK;
@@ -257,7 +275,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   DEVFREE(m->wimg_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
-  DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d);
+  DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
 }
@@ -976,7 +994,7 @@ extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
 struct khg_accs {
   khg_ctx* ctx = nullptr;
   int64_t sumG = 0; int32_t D = 0, num_tids = 0;
-  int64_t n = 0;
+  int64_t n = 0, cap = 0;
   double* buf_d = nullptr;
   double* occ() const { return buf_d; }
   double* mean() const { return buf_d + sumG; }
@@ -991,6 +1009,7 @@ extern "C" int khg_accs_create(khg_ctx* ctx, const khg_model* m, const khg_tm* t
   a->n = a->sumG * (1 + 2 * (int64_t)a->D) + a->num_tids + 1 + 8;
   int rc = dev_alloc(&a->buf_d, (size_t)a->n);
   if (rc) { delete a; return rc; }
+  a->cap = a->n;
   *out = a;
   return khg_accs_zero(ctx, a);
 }
@@ -1081,4 +1100,138 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     HIPCHK(hipGetLastError());
   }
   return KHG_OK;   // asynchronous: kernel-side errors surface at khg_ctx_sync / khg_accs_download
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: device M-step
+extern "C" int khg_model_set_weights(khg_ctx* ctx, khg_model* m, const float* weights) {
+  if (!ctx || !m || !weights) return khg_set_error(KHG_E_ARG, "khg_model_set_weights: bad arguments");
+  if (!m->weights_d) { int rc = dev_alloc(&m->weights_d, (size_t)m->sumG); if (rc) return rc; }
+  HIPCHK(hipMemcpyAsync(m->weights_d, weights, sizeof(float) * (size_t)m->sumG, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  m->has_weights = true;
+  return KHG_OK;
+}
+extern "C" int khg_model_num_gauss(const khg_model* m, int64_t* total, int32_t* gauss_off) {
+  if (!m) return khg_set_error(KHG_E_ARG, "khg_model_num_gauss: model is NULL");
+  if (total) *total = m->sumG;
+  if (gauss_off) std::memcpy(gauss_off, m->gauss_off.data(), sizeof(int32_t) * ((size_t)m->P + 1));
+  return KHG_OK;
+}
+extern "C" int khg_model_download(khg_ctx* ctx, const khg_model* m, float* weights, float* gconsts, float* miv, float* iv) {
+  if (!ctx || !m) return khg_set_error(KHG_E_ARG, "khg_model_download: bad arguments");
+  if (weights && !m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_download: the model has no weights (khg_model_set_weights)");
+  const size_t G = (size_t)m->sumG, n = G * m->D;
+  if (weights) HIPCHK(hipMemcpyAsync(weights, m->weights_d, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream));
+  if (gconsts) HIPCHK(hipMemcpyAsync(gconsts, m->gconsts_d, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream));
+  if (miv) HIPCHK(hipMemcpyAsync(miv, m->miv_d, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (iv) HIPCHK(hipMemcpyAsync(iv, m->iv_d, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+
+extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* acc, const khg_mle_options* o, uint16_t flags,
+                                    float* objf_change, float* count, int32_t* floored_elems, int32_t* floored_gauss,
+                                    int32_t* removed) {
+  if (!ctx || !m || !acc || !o) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: bad arguments");
+  if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: the model has no weights (khg_model_set_weights)");
+  if (acc->D != m->D || acc->sumG != m->sumG)
+    return khg_set_error(KHG_E_RUNTIME, "khg_model_mle_update: accumulator / model dimensions do not match");
+  if (flags & ~0x7) return khg_set_error(KHG_E_RUNTIME, "Flags in argument do not match the active accumulators");   // mle-diag-gmm.cc:252
+  { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
+  const int P = m->P, D = m->D;
+  int maxG = 0;
+  for (int p = 0; p < P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
+  const size_t lds = sizeof(double) * (256 + (size_t)maxG) + sizeof(float) * 5 * (size_t)maxG;
+  if (lds > 60 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_mle_update: more than ~2000 Gaussians in one pdf");
+  K4Res* res_d = nullptr;
+  int rc = dev_alloc(&res_d, (size_t)P);
+  if (rc) return rc;
+  K4Args a;
+  a.gauss_off = m->gauss_off_d; a.D = D;
+  a.occ = acc->occ(); a.macc = acc->mean(); a.vacc = acc->var();
+  a.w = m->weights_d; a.gc = m->gconsts_d; a.miv = m->miv_d; a.iv = m->iv_d;
+  a.res = res_d;
+  a.min_w = o->min_gaussian_weight; a.min_occ = o->min_gaussian_occupancy; a.min_var = o->min_variance;
+  a.remove_low = o->remove_low_count_gaussians; a.flags = flags;
+  {
+    KernelTimer kt(ctx, "k4_mle_update");
+    hipLaunchKernelGGL(k4_mle_update, dim3(P), dim3(256), lds, ctx->stream, a);
+  }
+  std::vector<K4Res> res((size_t)P);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(res.data(), res_d, sizeof(K4Res) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  DEVFREE(res_d);
+  if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  // totals in pdf order, float, as MleAmDiagGmmUpdate adds them (csrc/mle-am-diag-gmm.cc:177-193)
+  float tot_obj = 0.0f, tot_count = 0.0f;
+  int tfe = 0, tfg = 0, trm = 0;
+  std::vector<int32_t> new_off((size_t)P + 1);
+  int out = 0;
+  for (int p = 0; p < P; ++p) {
+    const K4Res& r = res[(size_t)p];
+    if (r.bad) return khg_set_error(KHG_E_RUNTIME, "pdf " + std::to_string(p) + ": not a number in gconst computation");
+    tot_obj += r.obj_change; tot_count += r.count; tfe += r.floored_elems; tfg += r.floored_gauss; trm += r.removed;
+    new_off[(size_t)p] = out;
+    out += r.newG;
+  }
+  new_off[(size_t)P] = out;
+  if (trm > 0) {
+    // some pdf shrank: move every pdf's rows to the new offsets in fresh arrays
+    int32_t* new_off_d = nullptr;
+    float *w2 = nullptr, *gc2 = nullptr, *miv2 = nullptr, *iv2 = nullptr;
+    rc = dev_upload(ctx, &new_off_d, new_off);
+    if (!rc) rc = dev_alloc(&w2, (size_t)out);
+    if (!rc) rc = dev_alloc(&gc2, (size_t)out);
+    if (!rc) rc = dev_alloc(&miv2, (size_t)out * D);
+    if (!rc) rc = dev_alloc(&iv2, (size_t)out * D);
+    if (!rc) {
+      KernelTimer kt(ctx, "k4_compact");
+      hipLaunchKernelGGL(k4_compact, dim3(P), dim3(256), 0, ctx->stream, m->gauss_off_d, new_off_d, D, m->weights_d, m->gconsts_d,
+                         m->miv_d, m->iv_d, w2, gc2, miv2, iv2);
+    }
+    if (!rc) {
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    }
+    DEVFREE(new_off_d);
+    if (rc) { DEVFREE(w2); DEVFREE(gc2); DEVFREE(miv2); DEVFREE(iv2); return rc; }
+    DEVFREE(m->weights_d); DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d);
+    m->weights_d = w2; m->gconsts_d = gc2; m->miv_d = miv2; m->iv_d = iv2;
+    m->gauss_off = new_off;
+    m->sumG = out;
+  }
+  rc = model_pack(ctx, m);   // new K1 tile image + -0.5*inv_vars from the updated parameters
+  if (rc) return rc;
+  if (objf_change) *objf_change = tot_obj;
+  if (count) *count = tot_count;
+  if (floored_elems) *floored_elems = tfe;
+  if (floored_gauss) *floored_gauss = tfg;
+  if (removed) *removed = trm;
+  return KHG_OK;
+}
+
+// After khg_model_mle_update removed Gaussians the accumulator block is laid out for fewer rows.
+extern "C" int khg_accs_relayout(khg_ctx* ctx, khg_accs* a, const khg_model* m) {
+  if (!ctx || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_relayout: bad arguments");
+  if (m->D != a->D) return khg_set_error(KHG_E_RUNTIME, "khg_accs_relayout: dimension mismatch");
+  const int64_t n = m->sumG * (1 + 2 * (int64_t)a->D) + a->num_tids + 1 + 8;
+  if (n > a->cap) {
+    DEVFREE(a->buf_d);
+    int rc = dev_alloc(&a->buf_d, (size_t)n);
+    if (rc) return rc;
+    a->cap = n;
+  }
+  a->sumG = m->sumG; a->n = n;
+  return khg_accs_zero(ctx, a);
+}
+extern "C" int khg_accs_download_trans(khg_ctx* ctx, const khg_accs* a, double* trans, double* scalars) {
+  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_download_trans: bad arguments");
+  { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
+  if (trans) HIPCHK(hipMemcpyAsync(trans, a->trans(), sizeof(double) * ((size_t)a->num_tids + 1), hipMemcpyDeviceToHost, ctx->stream));
+  if (scalars) HIPCHK(hipMemcpyAsync(scalars, a->scalars(), sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
 }

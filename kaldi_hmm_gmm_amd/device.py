@@ -60,7 +60,7 @@ class Context:
 class DeviceModel:
     """AmDiagGmm uploaded as the K1 tile image + K3 row-major copy."""
 
-    def __init__(self, ctx: Context, gauss_off, gconsts, means_invvars, inv_vars):
+    def __init__(self, ctx: Context, gauss_off, gconsts, means_invvars, inv_vars, weights=None):
         self.ctx = ctx
         go = _lib.as_np(gauss_off, np.int32)
         gc = _lib.as_np(gconsts, np.float32)
@@ -73,6 +73,46 @@ class DeviceModel:
         self.h = C.c_void_p()
         check(lib.khg_model_create(ctx.h, self.num_pdfs, self.dim, ptr(go, C.c_int32), ptr(gc, C.c_float),
                                    ptr(miv, C.c_float), ptr(iv, C.c_float), C.byref(self.h)))
+        if weights is not None:
+            self.set_weights(weights)
+
+    # -- K4: device M-step (khg_model_mle_update) ----------------------------------------------
+    def set_weights(self, weights):
+        """Mixture weights, only needed by mle_update (K1-K3 read them through gconsts)."""
+        w = _lib.as_np(weights, np.float32)
+        assert w.shape[0] == self.gauss_off[-1]
+        check(lib.khg_model_set_weights(self.ctx.h, self.h, ptr(w, C.c_float)))
+
+    def mle_update(self, accs: "DeviceAccs", opts=None, flags=0x7):
+        """MleAmDiagGmmUpdate (csrc/mle-am-diag-gmm.cc:153-202) on the device, from the accumulators where K3
+        (and the all-reduce) left them.  The handle is updated in place, gauss_off included.
+        -> dict(objf_change, count, floored_elements, floored_gaussians, removed)."""
+        o = _lib.MleOptionsC()
+        if opts is None:
+            lib.khg_mle_options_default(C.byref(o))
+        else:
+            o = opts._c() if hasattr(opts, "_c") else opts
+        oc, cnt = C.c_float(), C.c_float()
+        fe, fg, rm = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.khg_model_mle_update(self.ctx.h, self.h, accs.h, C.byref(o), C.c_uint16(int(flags) & 0xFFFF), C.byref(oc),
+                                       C.byref(cnt), C.byref(fe), C.byref(fg), C.byref(rm)))
+        if rm.value:
+            go = np.zeros(self.num_pdfs + 1, np.int32)
+            check(lib.khg_model_num_gauss(self.h, None, ptr(go, C.c_int32)))
+            self.gauss_off = go
+        return {"objf_change": oc.value, "count": cnt.value, "floored_elements": fe.value, "floored_gaussians": fg.value,
+                "removed": rm.value}
+
+    def download(self, weights=True):
+        """-> dict(gauss_off, weights, gconsts, means_invvars, inv_vars) of the handle's current parameters."""
+        G, D = int(self.gauss_off[-1]), self.dim
+        w = np.zeros(G, np.float32) if weights else None
+        gc = np.zeros(G, np.float32)
+        miv = np.zeros((G, D), np.float32)
+        iv = np.zeros((G, D), np.float32)
+        check(lib.khg_model_download(self.ctx.h, self.h, ptr(w, C.c_float) if weights else None, ptr(gc, C.c_float),
+                                     ptr(miv, C.c_float), ptr(iv, C.c_float)))
+        return {"gauss_off": self.gauss_off.copy(), "weights": w, "gconsts": gc, "means_invvars": miv, "inv_vars": iv}
 
     def close(self):
         if self.h:
@@ -297,6 +337,21 @@ class DeviceAccs:
         scal = buf[o: o + 8]
         return {"occ": occ, "mean_acc": mean, "var_acc": var, "trans_acc": trans, "total_frames": float(scal[0]),
                 "total_log_like": float(scal[1])}
+
+    def relayout(self, model: DeviceModel):
+        """After DeviceModel.mle_update removed Gaussians: adopt the model's new gauss_off (and zero)."""
+        check(lib.khg_accs_relayout(self.ctx.h, self.h, model.h))
+        self.sumG = int(model.gauss_off[-1])
+        n = C.c_int64()
+        check(lib.khg_accs_size(self.h, C.byref(n)))
+        self.size = n.value
+
+    def download_trans(self):
+        """Only the transition statistics and the scalar totals (what the host-side transition update needs)."""
+        tr = np.zeros(self.num_tids + 1, np.float64)
+        sc = np.zeros(8, np.float64)
+        check(lib.khg_accs_download_trans(self.ctx.h, self.h, ptr(tr, C.c_double), ptr(sc, C.c_double)))
+        return {"trans_acc": tr, "total_frames": float(sc[0]), "total_log_like": float(sc[1])}
 
     def download(self):
         buf = np.zeros(self.size, np.float64)

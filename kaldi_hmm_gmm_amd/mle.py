@@ -434,3 +434,20 @@ def mle_am_diag_gmm_update(config: MleDiagGmmOptions, amdiag_gmm_acc: AccumAmDia
     new_off, w, gc, miv, iv, oc, cnt, _, _, _ = _flat_update(config, go, occ, ma, va, acc_flags, int(flags), w, miv, iv)
     am_gmm.set_flat(new_off, w, gc, miv, iv)
     return oc, cnt
+
+
+def mle_am_diag_gmm_update_device(config: MleDiagGmmOptions, device_accs, flags, device_model, am_gmm: AmDiagGmm = None):
+    """mle_am_diag_gmm_update (csrc/mle-am-diag-gmm.cc:153-202) run on the GPU from the DeviceAccs block where
+    K3 / the all-reduce left the statistics (khg_model_mle_update, K4): `device_model` is updated in place and
+    is ready for the next loglikes / align / acc_stats pass without any accumulator download or parameter
+    upload.  am_gmm (optional) receives the new parameters (one 2*sumG*dim float download) -- pass it on the
+    iterations that write or mix up the model, leave it out otherwise.  -> (objf_change, count)."""
+    r = device_model.mle_update(device_accs, config, int(flags) & 0x7)
+    if r["removed"]:
+        device_accs.relayout(device_model)
+    if am_gmm is not None:
+        d = device_model.download()
+        if am_gmm.num_pdfs != device_model.num_pdfs:
+            raise KhgError("am_gmm->NumPdfs() does not match the device model")
+        am_gmm.set_flat(d["gauss_off"], d["weights"], d["gconsts"], d["means_invvars"], d["inv_vars"])
+    return r["objf_change"], r["count"]
