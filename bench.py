@@ -268,8 +268,34 @@ def main():
         ctxs[0].sync()
         tm3 = time.perf_counter()
         dm2.close()
-        m_step = {"accs_download_ms": (tm1 - tm0) * 1e3, "host_update_ms": (tm2 - tm1) * 1e3, "model_upload_ms": (tm3 - tm2) * 1e3,
-                  "gaussians_after": int(r_up[0][-1]), "note": "not part of value; host C++ update threaded over pdfs, tile image packed on the device"}
+        # the same M-step on the device (K4, khg_model_mle_update): from the accumulators in HBM to a model handle
+        # ready for the next pass; checked here against the host result at the bench's full size
+        dm.set_weights(model.weights)
+        ctxs[0].sync()
+        ctxs[0].set_timing(True)
+        tm4 = time.perf_counter()
+        r_dev = dm.mle_update(accs, mo, 7)
+        ctxs[0].sync()
+        tm5 = time.perf_counter()
+        k4_ms = dict(ctxs[0].timings())
+        ctxs[0].set_timing(False)
+        d_new = dm.download()
+        gc_ulps = np.abs(d_new["gconsts"].astype(np.float64) - r_up[2]) / np.spacing(np.abs(r_up[2]).astype(np.float32))
+        m_step = {"host": {"accs_download_ms": (tm1 - tm0) * 1e3, "update_ms": (tm2 - tm1) * 1e3, "model_upload_ms": (tm3 - tm2) * 1e3,
+                           "total_ms": (tm3 - tm0) * 1e3},
+                  "device": {"total_ms": (tm5 - tm4) * 1e3, "k4_mle_update_ms": k4_ms.get("k4_mle_update"),
+                             "k0_pack_tiles_ms": k4_ms.get("k0_pack_tiles"),
+                             "hbm_GBps": (int(model.gauss_off[-1]) * (D * 32 + 8)) / max(k4_ms.get("k4_mle_update", 0.0) * 1e-3, 1e-9) / 1e9,
+                             "params_bit_equal_to_host": bool(np.array_equal(d_new["weights"], r_up[1]) and
+                                                              np.array_equal(d_new["means_invvars"], r_up[3]) and
+                                                              np.array_equal(d_new["inv_vars"], r_up[4]) and
+                                                              np.array_equal(d_new["gauss_off"], r_up[0])),
+                             "gconsts_max_ulps_vs_host": float(gc_ulps.max()),
+                             "gconsts_equal_fraction": float((gc_ulps == 0).mean()),
+                             "objf_change": r_dev["objf_change"], "host_objf_change": r_up[5]},
+                  "gaussians_after": int(r_up[0][-1]),
+                  "note": "not part of value (SURVEY 8d: M-step reported separately); host = threaded C++ update between an "
+                          "accumulator download and a parameter upload; device = K4 on the accumulators where K3 left them"}
         traffic, traffic_src = pmc_traffic(frames_local / nb)
         out = {
             "metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss",

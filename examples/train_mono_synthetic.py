@@ -10,7 +10,11 @@ The reference's recipe needs the yesno audio, lhotse and kaldifst (none availabl
 synthetic generator keeps its shape: words YES / NO with optional silence, 3-state phones, 5-state
 silence, 23-dim features, beam 6 / retry 40, scales 0.1 / 1.0 / 0.1, the same realign schedule.
 
-Usage: python examples/train_mono_synthetic.py [--utts 60] [--iters 20]
+--resident runs the same schedule through khg.ResidentEm: features, graphs, alignments, accumulators and the
+model stay in HBM across passes, the GMM update runs on the device (K4); only the passes that mix up go through
+the host.
+
+Usage: python examples/train_mono_synthetic.py [--utts 60] [--iters 20] [--resident]
 """
 import argparse
 import os
@@ -57,6 +61,7 @@ def main():
     ap.add_argument("--dim", type=int, default=23)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--out", default="")
+    ap.add_argument("--resident", action="store_true", help="keep everything in HBM across passes (khg.ResidentEm)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     utts = make_data(args.utts, args.dim, rng)
@@ -75,6 +80,9 @@ def main():
         if not ok:
             raise SystemExit("equal_align failed")
         ali.append(a)
+
+    if args.resident:
+        return train_resident(args, utts, names, feats, transition_model, tree, am, train_graphs, ali)
 
     def accumulate():
         accs = khg.AccumAmDiagGmm()
@@ -115,6 +123,46 @@ def main():
     print(f"final: {ok}/{len(utts)} utterances aligned to their transcript; {r['num_error']} errors")
     if args.out:
         with open(args.out, "wb") as fh:                                                # :224-229 (torch.save of pickles)
+            pickle.dump({"acoustic_model": am, "transition_model": transition_model, "tree": tree}, fh)
+    return 0 if ok == len(utts) and r["num_error"] == 0 else 1
+
+
+def train_resident(args, utts, names, feats, transition_model, tree, am, train_graphs, ali, randn=None, log=print):
+    """The schedule of main() with the shard resident on the GPU."""
+    em = khg.ResidentEm(am, transition_model, train_graphs, feats, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+    em.set_alignments(ali)
+    num_gauss = am.num_pdfs
+    max_gauss = 4 * am.num_pdfs
+    max_iter_inc = max(1, args.iters * 3 // 8)
+    inc_gauss = (max_gauss - num_gauss) // max_iter_inc
+    tcfg = khg.MleTransitionUpdateConfig()
+    opts = khg.MleDiagGmmOptions()
+    opts.min_gaussian_occupancy = 3
+    em.accumulate()
+    em.update(tcfg, opts, mixup=num_gauss, update_flags="mvwt", randn=randn)
+    realign = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 38}
+    cfg = khg.AlignConfig(beam=6.0, retry_beam=40.0, careful=False)
+    for i in range(args.iters):
+        if i in realign:
+            em.boost_silence([SIL], boost=1.0)
+            r = em.align(cfg)
+            log(f"pass {i}: aligned {r['num_done']} utterances, {r['num_error']} errors, {r['num_retried']} retried, "
+                f"avg like/frame {r['tot_like'] / max(r['frame_count'], 1):.4f}")
+        em.accumulate()
+        info = em.update(tcfg, khg.MleDiagGmmOptions(), mixup=num_gauss, perturb_factor=0.01, power=0.2, min_count=20.0,
+                         update_flags="mvwt", randn=randn)
+        log(f"pass {i}: avg log-like per frame {info['avg_like']:.4f} over {info['frames']:.0f} frames, "
+            f"{em.num_gauss} Gaussians")
+        if i < max_iter_inc:
+            num_gauss += inc_gauss
+    em.sync_host()
+    em.close()
+    r = khg.gmm_align_compiled_batch(am, transition_model, names, train_graphs, feats, cfg, acoustic_scale=0.1,
+                                     transition_scale=1.0, self_loop_scale=0.1)
+    ok = sum(1 for w, u in zip(r["words"], utts) if w == u[1])
+    log(f"final: {ok}/{len(utts)} utterances aligned to their transcript; {r['num_error']} errors")
+    if args.out:
+        with open(args.out, "wb") as fh:
             pickle.dump({"acoustic_model": am, "transition_model": transition_model, "tree": tree}, fh)
     return 0 if ok == len(utts) and r["num_error"] == 0 else 1
 

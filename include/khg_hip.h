@@ -148,6 +148,8 @@ int khg_align(khg_ctx *ctx, const khg_tm *tm, khg_utts *u, const khg_align_confi
               float *like_h, int32_t *status_h);
 /* replace the resident alignment (e.g. an initial equal-align, egs/yesno/train.py:86-108) */
 int khg_ali_upload(khg_ctx *ctx, khg_utts *u, const int32_t *ali_h);
+/* the resident alignment back (0 on the frames of utterances that failed to align) */
+int khg_ali_download(khg_ctx *ctx, khg_utts *u, int32_t *ali_h);
 
 /* ---- K3: sufficient statistics ---------------------------------------------------------- */
 /* AccumAmDiagGmm (csrc/mle-am-diag-gmm.h:93-96) + transition stats (csrc/transition-model.h:176-189)
@@ -220,6 +222,15 @@ int khg_accs_relayout(khg_ctx *ctx, khg_accs *a, const khg_model *m);
 /* only the transition statistics [num_tids+1] and the 8 scalars (what TransitionModel::MleUpdate and the
  * log line of scripts/gmm_acc_stats_ali.py need) -- a few kB instead of the whole block */
 int khg_accs_download_trans(khg_ctx *ctx, const khg_accs *a, double *trans_h, double *scalars_h);
+
+/* any slice [first, first+count) of the fp64 block (e.g. occ = [0, sumG) for the mix-up targets of
+ * scripts/gmm_est.py:66-70) */
+int khg_accs_download_range(khg_ctx *ctx, const khg_accs *a, int64_t first, int64_t count,
+                            double *dst_h);
+/* scripts/gmm_boost_silence.py:10-45 on the handle: weights of the listed pdfs *= scale, their gconsts
+ * recomputed (DiagGmm::SetWeights + ComputeGconsts, csrc/diag-gmm.cc:103-147), tile image repacked */
+int khg_model_scale_weights(khg_ctx *ctx, khg_model *m, int32_t n, const int32_t *pdfs_h,
+                            float scale);
 
 /* TransitionModel::MleUpdate (csrc/transition-model.cc:657-750) + ComputeDerivedOfProbs (:339-359) */
 int khg_transition_mle_update(int32_t num_tstates, const int32_t *state2id,

@@ -18,6 +18,7 @@ from .mle import (AccumAmDiagGmm, AccumDiagGmm, GmmUpdateFlags, MleDiagGmmOption
                   get_split_targets, gmm_flags_to_str, ml_objective, mle_am_diag_gmm_update,
                   mle_am_diag_gmm_update_device, mle_diag_gmm_update,
                   str_to_gmm_flags)
+from .resident import ResidentEm  # noqa: F401
 from .scripts import (gmm_acc_stats_ali, gmm_acc_stats_ali_batch, gmm_align_compiled, gmm_align_compiled_batch,  # noqa: F401
                       gmm_boost_silence, gmm_est, gmm_init_mono)
 from .training_graph import TrainingGraphCompiler, TrainingGraphCompilerOptions, equal_align, generate_hmm_topo  # noqa: F401

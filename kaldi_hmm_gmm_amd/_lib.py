@@ -89,6 +89,7 @@ SIGNATURES = {
     "khg_align_config_default": (None, [C.POINTER(AlignConfigC)]),
     "khg_align": (C.c_int, [vp, vp, vp, C.POINTER(AlignConfigC), c_i32p, c_i32p, c_i64p, C.c_int64, c_f32p, c_i32p]),
     "khg_ali_upload": (C.c_int, [vp, vp, c_i32p]),
+    "khg_ali_download": (C.c_int, [vp, vp, c_i32p]),
     "khg_accs_create": (C.c_int, [vp, vp, vp, C.POINTER(vp)]),
     "khg_accs_destroy": (C.c_int, [vp]),
     "khg_accs_zero": (C.c_int, [vp, vp]),
@@ -110,6 +111,8 @@ SIGNATURES = {
     "khg_model_download": (C.c_int, [vp, vp, c_f32p, c_f32p, c_f32p, c_f32p]),
     "khg_accs_relayout": (C.c_int, [vp, vp, vp]),
     "khg_accs_download_trans": (C.c_int, [vp, vp, c_f64p, c_f64p]),
+    "khg_accs_download_range": (C.c_int, [vp, vp, C.c_int64, C.c_int64, c_f64p]),
+    "khg_model_scale_weights": (C.c_int, [vp, vp, C.c_int32, c_i32p, C.c_float]),
     "khg_transition_mle_update": (
         C.c_int,
         [C.c_int32, c_i32p, c_i32p, c_f64p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p],

@@ -989,6 +989,17 @@ extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
   return KHG_OK;
 }
 
+extern "C" int khg_ali_download(khg_ctx* ctx, khg_utts* u, int32_t* ali) {
+  if (!ctx || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_ali_download: no resident alignment");
+  int rc = wait_ali(ctx, u);
+  if (!rc) rc = check_err_flag(ctx, "khg_align");
+  if (rc) return rc;
+  if (u->N) HIPCHK(hipMemcpyAsync(ali, u->ali_d, sizeof(int32_t) * (size_t)u->N, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // accumulators + K3
 struct khg_accs {
@@ -1234,4 +1245,39 @@ extern "C" int khg_accs_download_trans(khg_ctx* ctx, const khg_accs* a, double* 
   if (scalars) HIPCHK(hipMemcpyAsync(scalars, a->scalars(), sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return KHG_OK;
+}
+extern "C" int khg_accs_download_range(khg_ctx* ctx, const khg_accs* a, int64_t first, int64_t count, double* dst) {
+  if (!ctx || !a || !dst || first < 0 || count < 0 || first + count > a->n) return khg_set_error(KHG_E_ARG, "khg_accs_download_range: bad arguments");
+  { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
+  if (count) HIPCHK(hipMemcpyAsync(dst, a->buf_d + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+
+extern "C" int khg_model_scale_weights(khg_ctx* ctx, khg_model* m, int32_t n, const int32_t* pdfs, float scale) {
+  if (!ctx || !m || n < 0 || (n > 0 && !pdfs)) return khg_set_error(KHG_E_ARG, "khg_model_scale_weights: bad arguments");
+  if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_scale_weights: the model has no weights (khg_model_set_weights)");
+  if (n == 0) return KHG_OK;
+  std::vector<int32_t> v(pdfs, pdfs + n);
+  for (int32_t p : v)
+    if (p < 0 || p >= m->P) return khg_set_error(KHG_E_ARG, "khg_model_scale_weights: pdf-id out of range");
+  int32_t *pdfs_d = nullptr, *bad_d = nullptr;
+  int rc = dev_upload(ctx, &pdfs_d, v);
+  if (!rc) rc = dev_alloc(&bad_d, 1);
+  int32_t bad = 0;
+  if (!rc) {
+    hipError_t e = hipMemsetAsync(bad_d, 0, sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k4_scale_weights, dim3(n), dim3(64), 0, ctx->stream, pdfs_d, m->gauss_off_d, m->D, scale, m->weights_d,
+                         m->gconsts_d, m->miv_d, m->iv_d, bad_d);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, bad_d, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  }
+  DEVFREE(pdfs_d); DEVFREE(bad_d);
+  if (rc) return rc;
+  if (bad) return khg_set_error(KHG_E_RUNTIME, "khg_model_scale_weights: not a number in gconst computation");
+  return model_pack(ctx, m);
 }

@@ -103,6 +103,12 @@ class DeviceModel:
         return {"objf_change": oc.value, "count": cnt.value, "floored_elements": fe.value, "floored_gaussians": fg.value,
                 "removed": rm.value}
 
+    def scale_weights(self, pdfs, scale: float):
+        """gmm_boost_silence (scripts/gmm_boost_silence.py:10-45) on the handle: weights of `pdfs` *= scale,
+        their gconsts recomputed."""
+        p = _lib.as_np(pdfs, np.int32)
+        check(lib.khg_model_scale_weights(self.ctx.h, self.h, p.shape[0], ptr(p, C.c_int32), float(scale)))
+
     def download(self, weights=True):
         """-> dict(gauss_off, weights, gconsts, means_invvars, inv_vars) of the handle's current parameters."""
         G, D = int(self.gauss_off[-1]), self.dim
@@ -260,6 +266,12 @@ class UtteranceSet:
         if not download:
             check(lib.khg_align(self.ctx.h, tm.h, self.h, C.byref(cfg), None, None, None, 0, None, None))
             return None
+        if download == "summary":          # per-utterance likelihood + status only; alignments stay in HBM for K3
+            like = np.zeros(self.n_utt, np.float32)
+            status = np.zeros(self.n_utt, np.int32)
+            check(lib.khg_align(self.ctx.h, tm.h, self.h, C.byref(cfg), None, None, None, 0, ptr(like, C.c_float),
+                                ptr(status, C.c_int32)))
+            return {"like": like, "status": status}
         N = int(self.frame_off[-1])
         ali = np.zeros(max(N, 1), np.int32)
         like = np.zeros(self.n_utt, np.float32)
@@ -275,6 +287,13 @@ class UtteranceSet:
         a = _lib.as_np(ali, np.int32)
         assert a.shape[0] == self.frame_off[-1]
         check(lib.khg_ali_upload(self.ctx.h, self.h, ptr(a, C.c_int32)))
+
+    def download_ali(self):
+        """The resident alignment (0 on the frames of utterances that failed to align)."""
+        n = int(self.frame_off[-1])
+        a = np.zeros(max(n, 1), np.int32)
+        check(lib.khg_ali_download(self.ctx.h, self.h, ptr(a, C.c_int32)))
+        return a[:n]
 
     def acc_stats(self, model: DeviceModel, tm: DeviceTransitions, accs: "DeviceAccs", weight: float = 1.0):
         check(lib.khg_acc_stats(self.ctx.h, model.h, tm.h, self.h, float(weight), accs.h))
@@ -345,6 +364,15 @@ class DeviceAccs:
         n = C.c_int64()
         check(lib.khg_accs_size(self.h, C.byref(n)))
         self.size = n.value
+
+    def download_range(self, first: int, count: int):
+        out = np.zeros(max(count, 1), np.float64)
+        check(lib.khg_accs_download_range(self.ctx.h, self.h, int(first), int(count), ptr(out, C.c_double)))
+        return out[:count]
+
+    def download_occ(self):
+        """Per-Gaussian occupancies only (what the mix-up targets of scripts/gmm_est.py:66-70 need)."""
+        return self.download_range(0, self.sumG)
 
     def download_trans(self):
         """Only the transition statistics and the scalar totals (what the host-side transition update needs)."""

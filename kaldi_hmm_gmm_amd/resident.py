@@ -1,0 +1,173 @@
+"""ResidentEm: the EM loop of the reference's recipe (egs/yesno/train.py:131-222 -- gmm_boost_silence,
+gmm_align_compiled, gmm_acc_stats_ali, gmm_est per pass) for a fixed shard of utterances whose features,
+decoding graphs, alignments, accumulators AND model stay in HBM across passes.
+
+The per-call scripts (scripts.py) mirror the reference's function signatures and therefore re-upload their
+arguments on every call; this class is what a multi-pass recipe uses instead -- the configuration BASELINE's
+metric is quoted on ("model, graphs and features resident in HBM").  Per pass:
+
+    align()       K1 (reachable cells only) + K2; alignments stay on the device
+    accumulate()  K3 into the fp64 block, then ONE all-reduce of the block when torch.distributed is
+                  initialised (utterances are sharded over ranks, csrc/mle-am-diag-gmm.cc:119-128 == gmm-sum-accs)
+    update()      transition update on the host (a few kB come down), GMM update on the device (K4,
+                  khg_model_mle_update); every rank holds the same all-reduced sums, so every rank computes the
+                  same new model and nothing is broadcast.  Only a pass that mixes up goes through the host
+                  (DiagGmm::Split draws random numbers; scripts/gmm_est.py:66-84).
+
+Utterances whose alignment fails contribute no statistics until they align again."""
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _gpu
+from ._lib import KhgError
+from .align import AlignConfig, FasterDecoderOptions
+from .device import ALIGN_ERROR, ALIGN_RETRIED, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
+from .diag_gmm import AmDiagGmm
+from .fst import StdVectorFst, concat_graphs
+from .mle import GmmUpdateFlags, MleDiagGmmOptions, get_split_targets, str_to_gmm_flags
+from .transition_model import MleTransitionUpdateConfig, TransitionModel, get_pdfs_for_phones
+
+
+class ResidentEm:
+    def __init__(self, am_gmm: AmDiagGmm, transition_model: TransitionModel, fsts: Sequence[StdVectorFst],
+                 feats: Sequence[np.ndarray], acoustic_scale: float = 1.0, transition_scale: float = 1.0,
+                 self_loop_scale: float = 1.0, ctx=None):
+        if len(fsts) != len(feats):
+            raise KhgError("ResidentEm: one decoding graph per utterance")
+        self.am, self.tm = am_gmm, transition_model
+        self.acoustic_scale, self.transition_scale, self.self_loop_scale = acoustic_scale, transition_scale, self_loop_scale
+        self.ctx = ctx or _gpu.default_context()
+        feats = [np.asarray(f, np.float32).reshape(-1, am_gmm.dim) for f in feats]
+        self.frame_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
+        allf = np.concatenate(feats) if feats else np.zeros((0, am_gmm.dim), np.float32)
+        self.dt = DeviceTransitions(self.ctx, np.asarray(transition_model.transition_id_to_pdf_array(), np.int32))
+        self._set_trans_cost()
+        self.us = UtteranceSet(self.ctx, self.dt, self.frame_off, allf, graphs=concat_graphs(list(fsts)))
+        self.dm: Optional[DeviceModel] = None
+        self.accs: Optional[DeviceAccs] = None
+        self._upload_model()
+        self.host_in_sync = True      # am_gmm holds the device model's parameters
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _set_trans_cost(self):
+        self.dt.set_trans_cost(self.tm.scaled_trans_cost(self.transition_scale, self.self_loop_scale))
+
+    def _upload_model(self):
+        go, gc, w, miv, iv = self.am.flat()
+        if self.accs is not None:
+            self.accs.close()
+        if self.dm is not None:
+            self.dm.close()
+        self.dm = DeviceModel(self.ctx, go, gc, miv, iv, weights=w)
+        self.accs = DeviceAccs(self.ctx, self.dm, self.dt)
+
+    def sync_host(self) -> AmDiagGmm:
+        """Bring am_gmm up to date with the device model (needed before writing or mixing up the model)."""
+        if not self.host_in_sync:
+            d = self.dm.download()
+            self.am.set_flat(d["gauss_off"], d["weights"], d["gconsts"], d["means_invvars"], d["inv_vars"])
+            self.host_in_sync = True
+        return self.am
+
+    @property
+    def num_gauss(self) -> int:
+        return int(self.dm.gauss_off[-1])
+
+    # -- the pass ------------------------------------------------------------------------------
+    def set_alignments(self, alis: Sequence[Sequence[int]]):
+        """E.g. the equal_align start of egs/yesno/train.py:86-108."""
+        a = np.concatenate([np.asarray(x, np.int32) for x in alis]) if len(alis) else np.zeros(0, np.int32)
+        if a.shape[0] != self.frame_off[-1]:
+            raise KhgError("ResidentEm.set_alignments: one transition-id per frame")
+        self.us.upload_ali(a)
+
+    def alignments(self) -> List[List[int]]:
+        """The resident alignments, downloaded (empty list for an utterance that failed to align)."""
+        a = self.us.download_ali()
+        out = []
+        for u in range(len(self.frame_off) - 1):
+            x = a[self.frame_off[u]: self.frame_off[u + 1]]
+            out.append(x.tolist() if x.size and x.all() else [])
+        return out
+
+    def boost_silence(self, silence_phones: List[int], boost: float = 1.5):
+        """scripts/gmm_boost_silence.py:10-45 on the device model (in place, like the script mutates am_gmm)."""
+        _, pdfs = get_pdfs_for_phones(self.tm, sorted(silence_phones))
+        self.dm.scale_weights(sorted(pdfs), boost)
+        self.host_in_sync = False
+
+    def align(self, config: AlignConfig, decoder_opts: FasterDecoderOptions = None) -> Dict[str, float]:
+        """gmm_align_compiled over the shard (scripts/gmm_align_compiled.py:10-79 + AlignUtteranceWrapper,
+        python/csrc/decoder-wrappers.cc:25-47) -> the counters the reference threads through its calls."""
+        if (config.retry_beam != 0 and config.retry_beam <= config.beam) or config.beam <= 0.0:
+            raise KhgError(f"Beams do not make sense: beam {config.beam}, retry-beam {config.retry_beam}")
+        if config.careful:
+            raise KhgError("ResidentEm.align: careful alignment changes the resident graphs; use align_batch")
+        o = decoder_opts or FasterDecoderOptions()
+        self.us.loglikes(self.dm, reachable_only=True)
+        r = self.us.align(self.dt, beam=config.beam, retry_beam=config.retry_beam, acoustic_scale=self.acoustic_scale,
+                          max_active=o.max_active, min_active=o.min_active, beam_delta=o.beam_delta, hash_ratio=o.hash_ratio,
+                          download="summary")
+        ok = (r["status"] & ALIGN_ERROR) == 0
+        T = np.diff(self.frame_off)
+        return {"num_done": int(ok.sum()), "num_error": int((~ok).sum()),
+                "num_retried": int(((r["status"] & ALIGN_RETRIED) != 0).sum()),
+                "tot_like": float(sum(float(x) for x in r["like"][ok])), "frame_count": int(T[ok].sum())}
+
+    def accumulate(self, weight: float = 1.0) -> Dict[str, float]:
+        """gmm_acc_stats_ali over the shard (scripts/gmm_acc_stats_ali.py:9-58) + the cross-rank sum."""
+        self.accs.zero()
+        self.us.acc_stats(self.dm, self.dt, self.accs, weight)
+        try:
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except ImportError:
+            multi = False
+        if multi:
+            import torch
+            self.ctx.sync()                               # K3 runs on the context's own stream
+            dist.all_reduce(self.accs.as_torch(), op=dist.ReduceOp.SUM)
+            torch.cuda.current_stream().synchronize()
+        self._tr = self.accs.download_trans()
+        return {"total_log_like": self._tr["total_log_like"], "total_frames": self._tr["total_frames"]}
+
+    def update(self, tcfg: MleTransitionUpdateConfig = None, gmm_opts: MleDiagGmmOptions = None, mixup: int = 0,
+               perturb_factor: float = 0.01, power: float = 0.2, min_count: float = 20.0, update_flags: str = "mvwt",
+               randn=None) -> Dict[str, float]:
+        """gmm_est (scripts/gmm_est.py:8-96) from the resident accumulators; returns its printed statistics."""
+        flags = str_to_gmm_flags(update_flags)
+        gmm_opts = gmm_opts or MleDiagGmmOptions()
+        tr = self._tr
+        info: Dict[str, float] = {}
+        if int(flags) & int(GmmUpdateFlags.kGmmTransitions):
+            objf_impr, count = self.tm.mle_update(tr["trans_acc"], tcfg or MleTransitionUpdateConfig())
+            info["transition_objf_impr"], info["transition_count"] = objf_impr, count
+            self._set_trans_cost()
+        pdf_occs = None
+        if mixup != 0:      # per-pdf occupancies of the statistics, before the update re-lays the block
+            occ = self.accs.download_occ()
+            go = self.dm.gauss_off
+            pdf_occs = np.asarray([occ[go[p]: go[p + 1]].sum() for p in range(self.dm.num_pdfs)], np.float32)
+        r = self.dm.mle_update(self.accs, gmm_opts, int(flags) & 0x7)
+        if r["removed"]:
+            self.accs.relayout(self.dm)
+        self.host_in_sync = False
+        tot_like, tot_t = np.float32(tr["total_log_like"]), np.float32(tr["total_frames"])
+        info.update(gmm_objf_impr=r["objf_change"], gmm_count=r["count"], frames=float(tot_t),
+                    avg_like=float(tot_like / tot_t) if tot_t else float("nan"), removed=r["removed"])
+        if mixup != 0:
+            targets = get_split_targets(pdf_occs, mixup, power, min_count)
+            cur = np.diff(self.dm.gauss_off)
+            if any(t > c for t, c in zip(targets, cur)):
+                am = self.sync_host()
+                am.split_by_count(state_occs=pdf_occs, target_components=mixup, perturb_factor=perturb_factor, power=power,
+                                  min_count=min_count, randn=randn)
+                self._upload_model()
+        return info
+
+    def close(self):
+        for o in (self.accs, self.us, self.dm, self.dt):
+            if o is not None:
+                o.close()
+        self.accs = self.us = self.dm = self.dt = None
