@@ -1086,7 +1086,24 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
     const bool use_mfma = maxG <= 128 && getenv("KHG_K3_VALU") == nullptr;
-    if (use_mfma) {
+    const char* k3form = getenv("KHG_K3_FORM");     // "block": the chunk-per-block MFMA form for every shape
+    const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && !(k3form && strcmp(k3form, "block") == 0);
+    if (use_wave) {
+      // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
+      const int nb = (maxG + 15) / 16;
+      const size_t lds = std::max<size_t>(sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 4 * 16 * 20),
+                                          sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
+      const int64_t avg_tiles = (u->N / std::max(1, m->P) + 15) / 16;
+      int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, (avg_tiles + 15) / 16), (4096 + m->P - 1) / m->P));
+      if (const char* e = getenv("KHG_K3_NY")) ny = std::max(1, atoi(e));
+      KernelTimer kt(ctx, "k3_accumulate");
+      switch (nb) {
+        case 1: hipLaunchKernelGGL((k3_accumulate_wave<1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL((k3_accumulate_wave<2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL((k3_accumulate_wave<3>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
+        default: hipLaunchKernelGGL((k3_accumulate_wave<4>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
+      }
+    } else if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
       const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions
       // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
