@@ -150,9 +150,18 @@ def test_align_end_to_end(ctx):
         assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
 
 
-@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (12, 128, 80, False)])
-def test_acc_stats_vs_oracle(ctx, P, G, D, ragged):
+@pytest.mark.parametrize("k3_form", ["wave", "block", "valu"])
+@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (30, 40, 13, True), (12, 128, 80, False)])
+def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, monkeypatch):
+    """All three K3 accumulate kernels: the wave-local MFMA form (default for <= 64 Gaussians, D <= 40), the
+    chunk-per-block MFMA form (KHG_K3_FORM=block; default for wider pdfs / features) and the VALU form
+    (KHG_K3_VALU=1; default above 128 Gaussians)."""
     from kaldi_hmm_gmm_amd import DeviceAccs
+
+    if k3_form == "block":
+        monkeypatch.setenv("KHG_K3_FORM", "block")
+    elif k3_form == "valu":
+        monkeypatch.setenv("KHG_K3_VALU", "1")
 
     m, gc, om, ut, cost = build(P, G, D, n_utt=12, seed=7, ragged=ragged, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
