@@ -888,12 +888,15 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   size_t max_npdf = 0;
   for (int i = 0; i < u->n_utt; ++i) max_npdf = std::max<size_t>(max_npdf, (size_t)(u->pdf_off[i + 1] - u->pdf_off[i]));
   // threads: one destination state each (up to 1024), KS states per thread beyond that
-  const int nthr = (int)std::min<size_t>(1024, (S + 63) / 64 * 64);
+  int nthr = (int)std::min<size_t>(1024, (S + 63) / 64 * 64);
+  int ks_force = 0;
+  if (const char* e = getenv("KHG_K2_KS")) ks_force = atoi(e);   // experiment: states per thread on the register-resident path
+  if (ks_force == 2 || ks_force == 4) nthr = (int)std::min<size_t>(1024, ((S + ks_force - 1) / ks_force + 63) / 64 * 64);
   const size_t nwave = nthr / 64;
   // register-resident path for the whole batch: in-degree <= 3 (up to 4 states per thread) or <= 6 (one state per thread)
   const bool deg6 = !u->has_eps && u->max_indeg > 3 && u->max_indeg <= 6 && S <= 1024;
   const bool fast = deg6 || (!u->has_eps && u->max_indeg <= 3 && S <= 4096);
-  const int KSsel = !fast ? 0 : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4));
+  const int KSsel = !fast ? 0 : ((ks_force == 2 || ks_force == 4) && !deg6 && S <= (size_t)1024 * ks_force ? ks_force : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4)));
   const size_t NSl = fast ? KSsel : 1;
   const size_t PERmax = (nwave * NSl * (deg6 ? 4 : 3) + 1) & ~size_t(1);   // u64 words per layer of packed back-pointers (see k2_viterbi_dp)
   const size_t LBmax = fast ? 8 * PERmax : ((S + 15) & ~size_t(15));
