@@ -181,11 +181,60 @@ class TrainingGraphCompiler:
     def compile_graph_from_text(self, transcript: Sequence[int]) -> StdVectorFst:
         """csrc/training-graph-compiler.cc:65-141 for a linear word sequence."""
         nodes, parcs, final_node, start, start_final = self._phone_graph(list(transcript))
-        # --- expand phones into transition-id arcs (no self-loops yet) ---
-        out = [[] for _ in range(nodes)]      # per state: (dst, tid, olabel, cost)
         finals = {final_node: 0.0}
         if start_final is not None:
             finals[start] = start_final
+        return self._expand(nodes, parcs, finals, start)
+
+    def compile_word_loop_graph(self, word_probs: Optional[Dict[int, float]] = None) -> StdVectorFst:
+        """A decoding graph for the same lexicon: a unigram word loop (every word of the lexicon, probability
+        ``word_probs[w]`` or uniform) with the lexicon's optional silence between words -- H o C o L o G for
+        G = a one-state unigram, built with the same expansion as the training graphs (transition-ids on the
+        input side, word-ids on the output side, "reorder" self-loops, epsilon-free).  What egs/yesno/decode.py
+        decodes with (there: HLG from the lang directory)."""
+        words = sorted(self.lexicon)
+        if not words:
+            raise KhgError("compile_word_loop_graph: empty lexicon")
+        wp = word_probs or {w: 1.0 / len(words) for w in words}
+        sil = self.sil_phone is not None
+        sil_cost = -math.log(self.sil_prob) if sil else 0.0
+        no_sil_cost = -math.log(1.0 - self.sil_prob) if sil else 0.0
+        nodes = 2 if sil else 1
+        loop, silst = 0, 1
+
+        def new():
+            nonlocal nodes
+            nodes += 1
+            return nodes - 1
+
+        arcs = []
+        for w in words:
+            for prob, phones in self.lexicon[w]:
+                if not phones:
+                    raise KhgError("TrainingGraphCompiler: empty pronunciations are not supported")
+                base0 = -math.log(float(prob)) - math.log(float(wp[w]))
+                cur = loop
+                for i, ph in enumerate(phones):
+                    first, last = i == 0, i == len(phones) - 1
+                    base, ol = (base0 if first else 0.0), (w if first else 0)
+                    if not last:
+                        nxt = new()
+                        arcs.append((cur, nxt, ph, ol, base))
+                        cur = nxt
+                    else:
+                        arcs.append((cur, loop, ph, ol, base + no_sil_cost))
+                        if sil:
+                            arcs.append((cur, silst, ph, ol, base + sil_cost))
+        if sil:
+            arcs.append((silst, loop, self.sil_phone, 0, 0.0))
+            arcs.append((loop, loop, self.sil_phone, 0, sil_cost))    # leading silence, folded like the lexicon's start epsilons
+        return self._expand(nodes, arcs, {loop: 0.0}, loop)
+
+    def _expand(self, nodes: int, parcs, finals: Dict[int, float], start: int) -> StdVectorFst:
+        """Phone-level graph -> transition-id graph: GetHmmAsFsa per phone arc, then
+        MakePrecedingInputSymbolsSameClass + AddSelfLoopsReorder (csrc/hmm-utils.cc:293-369)."""
+        # --- expand phones into transition-id arcs (no self-loops yet) ---
+        out = [[] for _ in range(nodes)]      # per state: (dst, tid, olabel, cost)
 
         def new_state():
             out.append([])
@@ -200,7 +249,6 @@ class TrainingGraphCompiler:
                         ids[x] = new_state()
                 first = h == 0
                 out[ids[h]].append((ids[d], tid, ol if first else 0, float(np.float32(c + (cost if first else 0.0)))))
-        # --- MakePrecedingInputSymbolsSameClass + AddSelfLoopsReorder (csrc/hmm-utils.cc:293-369) ---
         # a state copy per class (transition-state) of its incoming arcs
         fst = StdVectorFst()
         index = {}
