@@ -99,7 +99,7 @@ def main():
     opts = khg.MleDiagGmmOptions()
     opts.min_gaussian_occupancy = 3
     khg.gmm_est(am, accs, transition_model, tacc, tcfg, opts, mixup=num_gauss, update_flags="mvwt", verbose=False)   # :131-150
-    realign = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 38}
+    realign = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 38, 40, 42, 44, 46, 49, 52, 55, 58, 60, 65, 70, 75, 78, 79}   # egs/yesno/train.py:153
     cfg = khg.AlignConfig(beam=6.0, retry_beam=40.0, careful=False)
     for i in range(args.iters):
         if i in realign:
@@ -140,7 +140,7 @@ def train_resident(args, utts, names, feats, transition_model, tree, am, train_g
     opts.min_gaussian_occupancy = 3
     em.accumulate()
     em.update(tcfg, opts, mixup=num_gauss, update_flags="mvwt", randn=randn)
-    realign = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 38}
+    realign = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 38, 40, 42, 44, 46, 49, 52, 55, 58, 60, 65, 70, 75, 78, 79}   # egs/yesno/train.py:153
     cfg = khg.AlignConfig(beam=6.0, retry_beam=40.0, careful=False)
     for i in range(args.iters):
         if i in realign:

@@ -199,8 +199,9 @@ class TrainingGraphCompiler:
         sil = self.sil_phone is not None
         sil_cost = -math.log(self.sil_prob) if sil else 0.0
         no_sil_cost = -math.log(1.0 - self.sil_prob) if sil else 0.0
-        nodes = 2 if sil else 1
-        loop, silst = 0, 1
+        # nodes: start (before the leading-silence decision), loop (between words), sil (a word was followed by silence)
+        nodes = 3 if sil else 1
+        start, loop, silst = (0, 1, 2) if sil else (0, 0, 0)
 
         def new():
             nonlocal nodes
@@ -208,27 +209,30 @@ class TrainingGraphCompiler:
             return nodes - 1
 
         arcs = []
-        for w in words:
-            for prob, phones in self.lexicon[w]:
-                if not phones:
-                    raise KhgError("TrainingGraphCompiler: empty pronunciations are not supported")
-                base0 = -math.log(float(prob)) - math.log(float(wp[w]))
-                cur = loop
-                for i, ph in enumerate(phones):
-                    first, last = i == 0, i == len(phones) - 1
-                    base, ol = (base0 if first else 0.0), (w if first else 0)
-                    if not last:
-                        nxt = new()
-                        arcs.append((cur, nxt, ph, ol, base))
-                        cur = nxt
-                    else:
-                        arcs.append((cur, loop, ph, ol, base + no_sil_cost))
-                        if sil:
-                            arcs.append((cur, silst, ph, ol, base + sil_cost))
+        for src, extra in (((loop, 0.0), (start, no_sil_cost)) if sil else ((loop, 0.0),)):
+            for w in words:
+                for prob, phones in self.lexicon[w]:
+                    if not phones:
+                        raise KhgError("TrainingGraphCompiler: empty pronunciations are not supported")
+                    base0 = -math.log(float(prob)) - math.log(float(wp[w])) + extra
+                    cur = src
+                    for i, ph in enumerate(phones):
+                        first, last = i == 0, i == len(phones) - 1
+                        base, ol = (base0 if first else 0.0), (w if first else 0)
+                        if not last:
+                            nxt = new()
+                            arcs.append((cur, nxt, ph, ol, base))
+                            cur = nxt
+                        else:
+                            arcs.append((cur, loop, ph, ol, base + no_sil_cost))
+                            if sil:
+                                arcs.append((cur, silst, ph, ol, base + sil_cost))
+        finals = {loop: 0.0}
         if sil:
             arcs.append((silst, loop, self.sil_phone, 0, 0.0))
-            arcs.append((loop, loop, self.sil_phone, 0, sil_cost))    # leading silence, folded like the lexicon's start epsilons
-        return self._expand(nodes, arcs, {loop: 0.0}, loop)
+            arcs.append((start, loop, self.sil_phone, 0, sil_cost))   # the lexicon's start epsilons (prepare_lang.py:352-371), folded
+            finals[start] = no_sil_cost
+        return self._expand(nodes, arcs, finals, start)
 
     def _expand(self, nodes: int, parcs, finals: Dict[int, float], start: int) -> StdVectorFst:
         """Phone-level graph -> transition-id graph: GetHmmAsFsa per phone arc, then

@@ -157,3 +157,36 @@ def test_compiled_graphs_align_like_oracle(ctx):
             assert rb["alignment"][u] == want["ali"].tolist(), (beam, u)
             assert rb["words"][u] == want["words"].tolist()
         assert rb["num_done"] == len(fsts) and rb["num_error"] == 0
+
+
+def test_word_loop_decoding_graph_accepts_what_training_graphs_accept():
+    """compile_word_loop_graph (the decoding graph of examples/decode_synthetic.py): epsilon-free, the start
+    state is final, and any transition-id sequence a TRAINING graph of some transcript accepts is accepted by the
+    loop graph too, at the training graph's cost plus the unigram cost of its words (-log(1/3) each)."""
+    topo, cd, tm, gc = _setup()
+    loop = gc.compile_word_loop_graph()
+    assert loop.start == 0 and loop.is_final(0)
+    assert all(a.ilabel != 0 for s in range(loop.num_states) for a in loop.arcs(s))
+    rng = np.random.default_rng(5)
+    from kaldi_hmm_gmm_amd.training_graph import equal_align
+    for transcript in ([1], [2, 1], [3, 3, 2], [1, 2, 3, 1]):
+        g = gc.compile_graph_from_text(transcript)
+        for seed in range(4):
+            ok, ali = equal_align(g, 60 + 7 * seed, rand_seed=seed, num_retries=10)
+            assert ok
+            c_train, c_loop = _walk(g, ali), _walk(loop, ali)
+            assert c_train is not None and c_loop is not None
+            assert c_loop == pytest.approx(c_train + len(transcript) * math.log(3.0), abs=2e-4)
+    # and the olabels along an accepted path spell the transcript: follow the cheapest path greedily
+    g = gc.compile_graph_from_text([2, 3, 1])
+    ok, ali = equal_align(g, 80, rand_seed=1, num_retries=10)
+    cur = {loop.start: (0.0, [])}
+    for t in ali:
+        nxt = {}
+        for s, (c, w) in cur.items():
+            for a in loop.arcs(s):
+                if a.ilabel == t and c + a.weight < nxt.get(a.nextstate, (math.inf,))[0]:
+                    nxt[a.nextstate] = (c + a.weight, w + ([a.olabel] if a.olabel else []))
+        cur = nxt
+    finals = [(c + loop.final(s), w) for s, (c, w) in cur.items() if loop.is_final(s)]
+    assert min(finals)[1] == [2, 3, 1]
