@@ -2,6 +2,7 @@
 // host-side planning (model tile image, per-utterance pdf lists, in-arc CSR, K1 chunks) and
 // the launches of K1 / K2 / K3.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>   // DeviceRadixSort: the stable (pdf, frame) sort of K3's bucketing
 
 #include <algorithm>
 #include <climits>
@@ -359,6 +360,7 @@ struct khg_utts {
   bool ali_pending = false;
   // K3 scratch
   int32_t *pdf_count_d = nullptr, *pdf_cursor_d = nullptr, *frame_ids_d = nullptr;
+  uint32_t *sort_keys_d = nullptr, *sort_keys_out_d = nullptr, *sort_vals_d = nullptr; void* sort_tmp_d = nullptr; size_t sort_tmp_bytes = 0;
   int64_t* pdf_start_d = nullptr; unsigned long long* tid_count_d = nullptr;
   int32_t k3_P = 0, k3_tids = 0;
 };
@@ -553,6 +555,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
+  DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d);
   if (u->ev_dp) (void)hipEventDestroy(u->ev_dp);
   if (u->ev_ali) (void)hipEventDestroy(u->ev_ali);
   delete u;
@@ -1083,7 +1086,31 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       KernelTimer kt(ctx, "k3_bucket");
       hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
-      hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+      const char* bk = getenv("KHG_K3_BUCKET");      // "atomic": cursor-bump scatter (bucket order depends on the atomics)
+      if ((bk && strcmp(bk, "atomic") == 0) || u->N >= (int64_t)INT_MAX) {
+        hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+      } else {
+        // stable sort of (pdf, frame) pairs: frames of a pdf stay in frame order
+        int bits = 1;
+        while ((1 << bits) <= m->P) ++bits;            // keys are 0..P
+        if (!u->sort_keys_d) {
+          rc = dev_alloc(&u->sort_keys_d, (size_t)u->N);
+          if (!rc) rc = dev_alloc(&u->sort_keys_out_d, (size_t)u->N);
+          if (!rc) rc = dev_alloc(&u->sort_vals_d, (size_t)u->N);
+          if (rc) return rc;
+        }
+        size_t need = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
+                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+        if (need > u->sort_tmp_bytes) {
+          DEVFREE(u->sort_tmp_d);
+          HIPCHK(hipMalloc(&u->sort_tmp_d, need));
+          u->sort_tmp_bytes = need;
+        }
+        hipLaunchKernelGGL(k3_sort_keys, dim3(gb), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
+                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+      }
     }
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);

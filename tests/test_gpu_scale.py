@@ -91,6 +91,13 @@ def test_em_pass_properties_at_bench_shape(ctx, monkeypatch):
     x = ut.feats.astype(np.float64)
     np.testing.assert_allclose(got["mean_acc"].sum(0), x.sum(0), rtol=1e-5, atol=1e-6 * np.abs(x).sum(0).max())
     np.testing.assert_allclose(got["var_acc"].sum(0), (x * x).sum(0), rtol=1e-5)
+    # reproducibility: one block per pdf at this size, buckets in frame order, waves folded in order -> a second
+    # pass gives the same bits (total_log_like, a diagnostic summed across blocks with atomics, is excluded)
+    accs2 = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs2)
+    again = accs2.download()
+    for k in ("occ", "mean_acc", "var_acc", "trans_acc"):
+        assert np.array_equal(got[k], again[k]), k
     # per pdf: occupancy of a pdf's Gaussians = number of frames aligned to it
     per_pdf = np.add.reduceat(got["occ"], m.gauss_off[:-1].astype(np.int64))
     frames_pdf = np.bincount(m.id2pdf[res["ali"]], minlength=P)
