@@ -10,10 +10,9 @@ the graph, K2 runs the beam search (beam 13, no retry).  All utterances go throu
 is also decoded through the reference's FasterDecoder binding names.
 
 The flat-start recipe needs the reference's full 80-pass schedule (egs/yesno/train.py:152-153) and a couple of
-hundred utterances to find the right segmentation: with 40-100 utterances, or half the passes, it can settle in
-optima where word-final states absorb the optional silence (WER 15-40 %), and which optimum it reaches then depends
-on the last bits of the statistics (K3 sums frames in atomic-cursor order).  The defaults reach WER 0 % on the
-held-out utterances.
+hundred utterances to find the right segmentation: with 40-100 utterances it can settle in optima where word-final
+states absorb the optional silence (WER 15-40 %).  The run is reproducible bit for bit (seeded split
+perturbations, KHG_K3_NY=1); the defaults reach WER 0 % on the held-out utterances.
 
 Usage: python examples/decode_synthetic.py [--utts 200] [--iters 80]
 """
@@ -23,6 +22,8 @@ import sys
 import types
 
 import numpy as np
+
+os.environ.setdefault("KHG_K3_NY", "1")   # one K3 block per pdf: run-to-run reproducible statistics
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -53,7 +54,7 @@ def train(args, log=print):
     gc = TrainingGraphCompiler(tm, tree, lexicon, sil_phone=tr.SIL, sil_prob=0.5)
     graphs = gc.compile_graphs_from_text([u[1] for u in train_utts])
     ali = [equal_align(g, x.shape[0], rand_seed=3, num_retries=10)[1] for g, x in zip(graphs, feats)]
-    targs = types.SimpleNamespace(iters=args.iters, out="")
+    targs = types.SimpleNamespace(iters=args.iters, out="", seed=args.seed)
     rc = tr.train_resident(targs, train_utts, [u[0] for u in train_utts], feats, tm, tree, am, graphs, ali, log=lambda *a: None)
     log(f"trained on {len(train_utts)} utterances: {am.num_gauss} Gaussians, training alignments {'ok' if rc == 0 else 'INCOMPLETE'}")
     return tm, tree, am, lexicon, test_utts
@@ -95,7 +96,7 @@ def main():
     args = ap.parse_args()
     tm, tree, am, lexicon, test_utts = train(args)
     errs, nref, _, _ = decode(tm, tree, am, lexicon, test_utts)
-    return 0 if errs <= 0.25 * nref else 1
+    return 0 if errs <= 0.05 * nref else 1
 
 
 if __name__ == "__main__":

@@ -23,6 +23,8 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("KHG_K3_NY", "1")   # one K3 block per pdf: run-to-run reproducible statistics
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kaldi_hmm_gmm_amd as khg  # noqa: E402
 from kaldi_hmm_gmm_amd.training_graph import TrainingGraphCompiler, equal_align, generate_hmm_topo  # noqa: E402
@@ -98,7 +100,8 @@ def main():
     accs, tacc, ll = accumulate()
     opts = khg.MleDiagGmmOptions()
     opts.min_gaussian_occupancy = 3
-    khg.gmm_est(am, accs, transition_model, tacc, tcfg, opts, mixup=num_gauss, update_flags="mvwt", verbose=False)   # :131-150
+    randn = seeded_randn(args.seed + 1)
+    khg.gmm_est(am, accs, transition_model, tacc, tcfg, opts, mixup=num_gauss, update_flags="mvwt", verbose=False, randn=randn)   # :131-150
     realign = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 38, 40, 42, 44, 46, 49, 52, 55, 58, 60, 65, 70, 75, 78, 79}   # egs/yesno/train.py:153
     cfg = khg.AlignConfig(beam=6.0, retry_beam=40.0, careful=False)
     for i in range(args.iters):
@@ -111,7 +114,7 @@ def main():
                   f"avg like/frame {r['tot_like'] / max(r['frame_count'], 1):.4f}")
         accs, tacc, ll = accumulate()
         info = khg.gmm_est(am, accs, transition_model, tacc, tcfg, khg.MleDiagGmmOptions(), mixup=num_gauss, perturb_factor=0.01,
-                           power=0.2, min_count=20.0, update_flags="mvwt", verbose=False)
+                           power=0.2, min_count=20.0, update_flags="mvwt", verbose=False, randn=randn)
         print(f"pass {i}: avg log-like per frame {info['avg_like']:.4f} over {info['frames']:.0f} frames, "
               f"{am.num_gauss} Gaussians")
         if i < max_iter_inc:
@@ -127,8 +130,15 @@ def main():
     return 0 if ok == len(utts) and r["num_error"] == 0 else 1
 
 
+def seeded_randn(seed):
+    """DiagGmm::Split draws its perturbations from the global RNG in the reference; a seeded stream makes a run reproducible."""
+    rng = np.random.default_rng(seed)
+    return lambda d: rng.standard_normal(d).astype(np.float32)
+
+
 def train_resident(args, utts, names, feats, transition_model, tree, am, train_graphs, ali, randn=None, log=print):
     """The schedule of main() with the shard resident on the GPU."""
+    randn = randn or seeded_randn(getattr(args, "seed", 3) + 1)
     em = khg.ResidentEm(am, transition_model, train_graphs, feats, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
     em.set_alignments(ali)
     num_gauss = am.num_pdfs
