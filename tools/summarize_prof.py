@@ -19,10 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r1"
-OURS = ("k1_loglikes", "k1p_", "k2_viterbi", "k3_", "k4_", "k0_pack")
+OURS = ("k1_loglikes", "k1p_", "k2_viterbi", "k3_", "k4_", "k0_pack", "rocprim")
 
 
 def short(name):
+    if "rocprim" in name:      # K3's stable (pdf, frame) radix sort (hipcub::DeviceRadixSort) -- and torch's own scans
+        return "rocprim::" + ("radix_sort_onesweep" if "radix_sort" in name else name.split("detail::")[-1][:40])
     return name.split("(")[0].replace("void ", "") if any(o in name for o in OURS) else name[:60]
 
 
