@@ -183,6 +183,61 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, monkeypatch):
     np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
 
 
+@pytest.mark.parametrize("k3_form", ["wave", "block", "valu"])
+@pytest.mark.parametrize("P,G,D", [(30, 64, 40), (30, 24, 23), (12, 128, 80)])
+def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, monkeypatch):
+    """The synthetic model's Gaussians are ~27 sigma apart (posteriors are one-hot, any softmax would do); here the
+    means are pulled together so every frame spreads its posterior over many components and the softmax, the
+    per-frame normalisation and the gamma-weighted sums are all exercised against the oracle."""
+    from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
+
+    if k3_form == "block":
+        monkeypatch.setenv("KHG_K3_FORM", "block")
+    elif k3_form == "valu":
+        monkeypatch.setenv("KHG_K3_VALU", "1")
+    m, _, _, ut, cost = build(P, G, D, n_utt=12, seed=13, max_phones=5)
+    means = (0.12 * m.means).astype(np.float32)
+    miv = (means * m.inv_vars).astype(np.float32)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, miv)
+    om = orc.OModel(m.gauss_off, gc, miv, m.inv_vars)
+    feats = (0.12 * ut.feats + np.random.default_rng(2).standard_normal(ut.feats.shape)).astype(np.float32)
+    dm = DeviceModel(ctx, m.gauss_off, gc, miv, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    us = UtteranceSet(ctx, tm, ut.frame_off, feats)
+    us.upload_ali(ut.ref_ali)
+    accs = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs, weight=0.75)
+    got = accs.download()
+    oa = orc.OAccs(int(m.gauss_off[-1]), D, m.num_tids)
+    for u in range(us.n_utt):
+        sl = slice(ut.frame_off[u], ut.frame_off[u + 1])
+        orc.acc_stats_ali(om, m.id2pdf, feats[sl], ut.ref_ali[sl], oa, weight=0.75)
+    # the posteriors really are diffuse: the largest component takes well under all of a frame's mass on average
+    per_pdf_max = np.maximum.reduceat(oa.occ, m.gauss_off[:-1].astype(np.int64))
+    per_pdf_sum = np.add.reduceat(oa.occ, m.gauss_off[:-1].astype(np.int64))
+    assert (per_pdf_max[per_pdf_sum > 0] / per_pdf_sum[per_pdf_sum > 0]).mean() < 0.5
+    assert got["total_frames"] == pytest.approx(oa.total_frames, rel=1e-12)
+    assert got["total_log_like"] == pytest.approx(oa.total_log_like, rel=2e-6)
+    # Stated tolerance for diffuse posteriors: a posterior is exp(ll_g - ll) of two fp32 log-likelihoods, each within
+    # 1e-5 + 1e-6*B (B ~ 60 here) of the exact value in EITHER implementation (different summation orders of the
+    # D-term dot products), so gamma -- and sums of gammas -- agree to ~1e-4 relative, not to the 2e-5 of the
+    # one-hot case above.
+    np.testing.assert_allclose(got["occ"], oa.occ, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-4, atol=2e-5 * np.abs(oa.mean_acc).max())
+    np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-4, atol=2e-5 * np.abs(oa.var_acc).max())
+    # and against an fp64 evaluation of the same posteriors (what both approximate) at the same tolerance
+    x = feats.astype(np.float64)
+    pdf = m.id2pdf[ut.ref_ali]
+    occ64 = np.zeros_like(oa.occ)
+    for p in np.unique(pdf):
+        a, b = int(m.gauss_off[p]), int(m.gauss_off[p + 1])
+        xs = x[pdf == p]
+        ll = gc[a:b].astype(np.float64)[None, :] + xs @ miv[a:b].astype(np.float64).T - 0.5 * (xs * xs) @ m.inv_vars[a:b].astype(np.float64).T
+        g = np.exp(ll - ll.max(1, keepdims=True))
+        occ64[a:b] = 0.75 * (g / g.sum(1, keepdims=True)).sum(0)
+    np.testing.assert_allclose(got["occ"], occ64, rtol=2e-4, atol=1e-6)
+
+
 def _first_frames(g, u, id2pdf, pdfs):
     """Fewest emitting arcs before an arc with each listed pdf can be taken (0-1 BFS from the start state)."""
     from collections import deque
