@@ -53,6 +53,40 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
+@pytest.mark.parametrize("k1", ["pdf", "utt"])
+@pytest.mark.parametrize("P,G,D", [(30, 64, 40), (24, 20, 13), (12, 128, 80)])
+def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
+    """Same bound with the means pulled together (many components contribute to every log-sum-exp instead of one)."""
+    import dataclasses
+
+    monkeypatch.setenv("KHG_K1", k1)
+    m, _, _, ut, cost = build(P, G, D, n_utt=6, seed=P + G + 1, max_phones=5)
+    means = (0.12 * m.means).astype(np.float32)
+    m2 = dataclasses.replace(m, means=means, means_invvars=(means * m.inv_vars).astype(np.float32))
+    gc = orc.model_gconsts(m2.gauss_off, m2.weights, m2.inv_vars, m2.means_invvars)
+    om = orc.OModel(m2.gauss_off, gc, m2.means_invvars, m2.inv_vars)
+    feats = (0.12 * ut.feats + np.random.default_rng(4).standard_normal(ut.feats.shape)).astype(np.float32)
+    ut2 = dataclasses.replace(ut, feats=feats)
+    dm, tm, us = _device(ctx, m2, gc, ut2, cost)
+    us.loglikes(dm)
+    got = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    spread = []
+    for u in range(us.n_utt):
+        pl = pdfs[poff[u]: poff[u + 1]]
+        x = utt_feats(ut2, u)
+        exact, bound = exact_loglikes(m2, gc, x, pl)
+        tol = LL_ATOL + LL_RTOL * bound
+        assert (np.abs(got[u] - exact) <= tol).all()
+        assert (np.abs(got[u] - orc.loglikes_matrix(om, x, pl)) <= 2 * tol).all()
+        # log-sum-exp minus the best single component: > 0.5 nats when several components matter
+        p0 = int(pl[0]); a, b = int(m2.gauss_off[p0]), int(m2.gauss_off[p0 + 1])
+        xs = x.astype(np.float64)
+        comp = gc[a:b].astype(np.float64)[None] + xs @ m2.means_invvars[a:b].astype(np.float64).T - 0.5 * (xs * xs) @ m2.inv_vars[a:b].astype(np.float64).T
+        spread.append(float((exact[0] - comp.max(1)).mean()))
+    assert np.mean(spread) > 0.5
+
+
 @pytest.fixture(params=["pdf", "utt"])
 def k1_form(request, monkeypatch):
     """Both K1 forms: pdf-major (default for <= 64 Gaussians per pdf) and utterance-major (KHG_K1=utt)."""
