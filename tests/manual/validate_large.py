@@ -1,7 +1,7 @@
 """One-off larger end-to-end check (not part of pytest): K1 -> K2 -> K3 through the C-ABI vs the oracle pipeline on a few
 hundred bench-like utterances (long, ~75 pdfs each, 64 Gaussians)."""
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
 import numpy as np
 from helpers import build, oracle_graph, utt_feats
 from oracle import oracle as orc
