@@ -81,3 +81,13 @@ def test_gpu_stats_and_m_step_match_golden(ctx):
     np.testing.assert_allclose(r[3], G["new_means_invvars"], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(r[4], G["new_inv_vars"], rtol=2e-3)
     assert r[5] == pytest.approx(float(G["objf_change"]), rel=1e-3)
+    # the same M-step on the device (K4), from the accumulators where K3 left them
+    dm.set_weights(G["weights"])
+    rd = dm.mle_update(accs, khg.MleDiagGmmOptions(min_gaussian_occupancy=3.0), 0x7)
+    d = dm.download()
+    assert (d["gauss_off"] == G["new_gauss_off"]).all()
+    assert np.array_equal(d["weights"], r[1]) and np.array_equal(d["inv_vars"], r[4]) and np.array_equal(d["means_invvars"], r[3])
+    np.testing.assert_allclose(d["weights"], G["new_weights"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(d["means_invvars"], G["new_means_invvars"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(d["inv_vars"], G["new_inv_vars"], rtol=2e-3)
+    assert rd["objf_change"] == pytest.approx(float(G["objf_change"]), rel=1e-3)
