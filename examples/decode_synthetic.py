@@ -12,7 +12,7 @@ is also decoded through the reference's FasterDecoder binding names.
 The flat-start recipe needs the reference's full 80-pass schedule (egs/yesno/train.py:152-153) and a couple of
 hundred utterances to find the right segmentation: with 40-100 utterances it can settle in optima where word-final
 states absorb the optional silence (WER 15-40 %).  The run is reproducible bit for bit (seeded split
-perturbations, KHG_K3_NY=1); the defaults reach WER 0 % on the held-out utterances.
+perturbations, ordered K3 reductions); the defaults reach WER 0 % on the held-out utterances.
 
 Usage: python examples/decode_synthetic.py [--utts 200] [--iters 80]
 """
@@ -22,8 +22,6 @@ import sys
 import types
 
 import numpy as np
-
-os.environ.setdefault("KHG_K3_NY", "1")   # one K3 block per pdf: run-to-run reproducible statistics
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -23,8 +23,6 @@ import sys
 
 import numpy as np
 
-os.environ.setdefault("KHG_K3_NY", "1")   # one K3 block per pdf: run-to-run reproducible statistics
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kaldi_hmm_gmm_amd as khg  # noqa: E402
 from kaldi_hmm_gmm_amd.training_graph import TrainingGraphCompiler, equal_align, generate_hmm_topo  # noqa: E402

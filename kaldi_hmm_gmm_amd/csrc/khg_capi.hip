@@ -361,6 +361,7 @@ struct khg_utts {
   // K3 scratch
   int32_t *pdf_count_d = nullptr, *pdf_cursor_d = nullptr, *frame_ids_d = nullptr;
   uint32_t *sort_keys_d = nullptr, *sort_keys_out_d = nullptr, *sort_vals_d = nullptr; void* sort_tmp_d = nullptr; size_t sort_tmp_bytes = 0;
+  double *k3_part_d = nullptr, *k3_llpart_d = nullptr; size_t k3_part_n = 0, k3_llpart_n = 0;   // wave-form K3: slice images / per-pdf log-likes
   int64_t* pdf_start_d = nullptr; unsigned long long* tid_count_d = nullptr;
   int32_t k3_P = 0, k3_tids = 0;
 };
@@ -556,6 +557,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
   DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d);
+  DEVFREE(u->k3_part_d); DEVFREE(u->k3_llpart_d);
   if (u->ev_dp) (void)hipEventDestroy(u->ev_dp);
   if (u->ev_ali) (void)hipEventDestroy(u->ev_ali);
   delete u;
@@ -1079,7 +1081,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
   a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
   a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
   a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
-  a.weight = weight; a.err_flag = ctx->err_flag_d;
+  a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr;
   if (u->N > 0) {
     const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
     {
@@ -1126,13 +1128,35 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       const int64_t avg_tiles = (u->N / std::max(1, m->P) + 15) / 16;
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, (avg_tiles + 15) / 16), (4096 + m->P - 1) / m->P));
       if (const char* e = getenv("KHG_K3_NY")) ny = std::max(1, atoi(e));
+      // per-pdf log-like partials (always) and, with several blocks per pdf, the slice images they park
+      const size_t nsum1 = (size_t)nb * 16 * 80 + (size_t)nb * 16 + 1;
+      if (u->k3_llpart_n < (size_t)m->P) {
+        DEVFREE(u->k3_llpart_d);
+        rc = dev_alloc(&u->k3_llpart_d, (size_t)m->P);
+        if (rc) return rc;
+        u->k3_llpart_n = (size_t)m->P;
+      }
+      if (ny > 1 && u->k3_part_n < (size_t)m->P * ny * nsum1) {
+        DEVFREE(u->k3_part_d);
+        rc = dev_alloc(&u->k3_part_d, (size_t)m->P * ny * nsum1);
+        if (rc) return rc;
+        u->k3_part_n = (size_t)m->P * ny * nsum1;
+      }
+      HIPCHK(hipMemsetAsync(u->k3_llpart_d, 0, sizeof(double) * (size_t)m->P, ctx->stream));
+      a.ll_part = u->k3_llpart_d;
+      a.part = ny > 1 ? u->k3_part_d : nullptr;
       KernelTimer kt(ctx, "k3_accumulate");
       switch (nb) {
-        case 1: hipLaunchKernelGGL((k3_accumulate_wave<1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL((k3_accumulate_wave<2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
-        case 3: hipLaunchKernelGGL((k3_accumulate_wave<3>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
-        default: hipLaunchKernelGGL((k3_accumulate_wave<4>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a); break;
+        case 1: hipLaunchKernelGGL((k3_accumulate_wave<1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<1>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
+        case 2: hipLaunchKernelGGL((k3_accumulate_wave<2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<2>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
+        case 3: hipLaunchKernelGGL((k3_accumulate_wave<3>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<3>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
+        default: hipLaunchKernelGGL((k3_accumulate_wave<4>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<4>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
       }
+      hipLaunchKernelGGL(k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
     } else if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
       const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions

@@ -59,5 +59,5 @@ def test_decode_example_word_loop_graph_vs_oracle(ctx):
         want = orc.align_utterance(og, om, id2pdf, u[2], acoustic_scale=0.1, beam=13.0, retry_beam=0.0)
         assert want["status"] == 0 and r["ok"]
         assert r["alignment"] == want["ali"].tolist() and r["words"] == want["words"].tolist()
-    # reproducible run (seeded split perturbations, KHG_K3_NY=1): the 80-pass schedule on 200 utterances recovers every transcript
+    # reproducible run (seeded split perturbations, ordered K3 reductions): the 80-pass schedule on 200 utterances recovers every transcript
     assert errs <= 0.05 * nref, (errs, nref)

@@ -272,6 +272,29 @@ def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, monkey
     np.testing.assert_allclose(got["occ"], occ64, rtol=2e-4, atol=1e-6)
 
 
+def test_acc_stats_reproducible_bit_for_bit(ctx, monkeypatch):
+    """Wave-form K3 (the default for <= 64 Gaussians, D <= 40): stable bucket sort, per-pdf tile order, waves and pdf
+    slices folded in a fixed order, one atomic per cell -- repeated passes give identical bits, with one block per pdf
+    and with a pdf cut into several blocks (small models), scalars included."""
+    from kaldi_hmm_gmm_amd import DeviceAccs
+
+    m, gc, om, ut, cost = build(12, 40, 23, n_utt=60, seed=21, ragged=True, max_phones=8)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.upload_ali(ut.ref_ali)
+    for ny in ("1", "7"):
+        monkeypatch.setenv("KHG_K3_NY", ny)
+        runs = []
+        for _ in range(3):
+            accs = DeviceAccs(ctx, dm, tm)
+            us.acc_stats(dm, tm, accs, weight=0.3)
+            buf = np.zeros(accs.size, np.float64)
+            st = accs.download()
+            runs.append(np.concatenate([st["occ"], st["mean_acc"].ravel(), st["var_acc"].ravel(), st["trans_acc"],
+                                        [st["total_frames"], st["total_log_like"]]]))
+        assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), ny
+        assert runs[0][-2] == pytest.approx(0.3 * ut.frame_off[-1], rel=1e-6)
+
+
 def _first_frames(g, u, id2pdf, pdfs):
     """Fewest emitting arcs before an arc with each listed pdf can be taken (0-1 BFS from the start state)."""
     from collections import deque
