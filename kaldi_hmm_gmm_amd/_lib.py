@@ -22,6 +22,16 @@ def _load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). kaldi_hmm_gmm_amd has no CPU fallback."
         )
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same
+    # SONAME as /opt/rocm's, which this library is linked against).  Loaded torch-first, the dynamic linker resolves
+    # our libamdhip64.so.7 to the copy already in the process and everything shares one runtime (streams, RCCL
+    # tensors aliasing our buffers).  Loaded the other way round, torch later brings in its bundled copy as a SECOND
+    # runtime, whose HSA layer cannot open the device any more ("No HIP GPUs are available").  So when torch is
+    # installed, let it load its runtime first; without torch the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return C.CDLL(LIB_PATH)
 
 

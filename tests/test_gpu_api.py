@@ -404,3 +404,42 @@ def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, monkeypatc
             if not (want["status"] & 1):
                 assert (a == want["ali"]).all(), (kw, u)
     assert seen > 20, "the fallback decoder was hardly exercised"
+
+
+def test_accs_as_torch_aliases_the_device_block_and_all_reduces(ctx):
+    """DeviceAccs.as_torch(): the zero-copy torch view bench.py / ResidentEm hand to torch.distributed.all_reduce
+    (RCCL).  One-rank process group: the collective runs on the aliased memory and leaves the sums in place."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
+
+    m, gc, om, ut, cost = build(12, 8, 16, n_utt=6, seed=5, max_phones=4)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats)
+    us.upload_ali(ut.ref_ali)
+    accs = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs)
+    before = accs.download()
+    ctx.sync()
+    t = accs.as_torch()
+    assert t.dtype == torch.float64 and t.numel() == accs.size and t.is_cuda and t.data_ptr() == accs.device_ptr()
+    assert float(t[: accs.sumG].sum()) == pytest.approx(before["occ"].sum(), rel=1e-12)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.mul_(2.0)                                     # visible through the C-ABI download: same memory
+        torch.cuda.synchronize()
+        after = accs.download()
+        np.testing.assert_array_equal(after["occ"], 2.0 * before["occ"])
+        np.testing.assert_array_equal(after["mean_acc"], 2.0 * before["mean_acc"])
+        assert after["total_frames"] == 2.0 * before["total_frames"]
+    finally:
+        if created:
+            dist.destroy_process_group()
