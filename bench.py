@@ -120,6 +120,12 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record of rank 0.  RCCL prints a version banner through C stdio on
+    # stdout (flushed at exit, i.e. AFTER anything Python printed), torch may warn there too: everything else in
+    # the process is pointed at stderr and the record is written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -132,9 +138,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     torch.cuda.set_device(local)
-    if world > 1:
+    # KHG_BENCH_FORCE_DIST=1: run the collective code path (process group, all-reduce of the accumulator block, max /
+    # sum of the timings) in a one-rank group -- the only way to exercise it on a one-GPU box
+    dist_on = world > 1 or os.environ.get("KHG_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     from kaldi_hmm_gmm_amd import Context, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet, synth
     from kaldi_hmm_gmm_amd import _lib
@@ -183,7 +196,7 @@ def main():
         fsub = feats[int(fo[0]): int(fo[-1])]
         sets.append(UtteranceSet(ctxs[b % len(ctxs)], tm, fo - fo[0], (fsub.data_ptr(), feats), dim=D, graphs=sub))
     accs = DeviceAccs(ctxs[0], dm, tm)
-    acc_t = accs.as_torch() if world > 1 else None
+    acc_t = accs.as_torch() if dist_on else None
 
     T = np.diff(ut.frame_off)
     npdf = np.concatenate([np.diff(s_.pdf_lists()[0]) for s_ in sets])
@@ -214,7 +227,7 @@ def main():
             s_.acc_stats(dm, tm, accs)
         for st in streams[1:]:
             ev_b.record(st); streams[0].wait_event(ev_b)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(acc_t)                    # torch's current stream is stream 0
 
     for _ in range(args.warmup):
@@ -223,14 +236,14 @@ def main():
     for c in ctxs:
         c.sync()                                      # also surfaces deferred kernel errors
         c.set_timing(True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -242,7 +255,7 @@ def main():
     n_local_launches = args.steps * nb
 
     frames_total = frames_local
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt, float(frames_local)], device=dev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -334,10 +347,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        record = json.dumps(out)
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (record + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
