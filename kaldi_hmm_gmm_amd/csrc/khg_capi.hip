@@ -500,7 +500,8 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
           out_inidx[a] = (int32_t)(pos - a0);
         }
       }
-      u->bp_off[i + 1] = u->bp_off[i] + (T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 512);  // >= 512 B per layer: room for the packed fast-path format (<= 4 bits per state, whole waves)
+      // generic path: one byte per (layer, state); fast path: one dword per (group of eight layers, lane), whole waves
+      u->bp_off[i + 1] = u->bp_off[i] + std::max<int64_t>((T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 512), ((T >> 3) + 1) * (S + 256) * 4);
       u->path_off[i + 1] = u->path_off[i] + T + S + 8;
       u->words_off[i + 1] = u->words_off[i] + nwords;
     }
@@ -903,11 +904,11 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const bool fast = deg6 || (!u->has_eps && u->max_indeg <= 3 && S <= 4096);
   const int KSsel = !fast ? 0 : ((ks_force == 2 || ks_force == 4) && !deg6 && S <= (size_t)1024 * ks_force ? ks_force : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4)));
   const size_t NSl = fast ? KSsel : 1;
-  const size_t PERmax = (nwave * NSl * (deg6 ? 4 : 3) + 1) & ~size_t(1);   // u64 words per layer of packed back-pointers (see k2_viterbi_dp)
-  const size_t LBmax = fast ? 8 * PERmax : ((S + 15) & ~size_t(15));
-  // cur | nxt | packed bp block (fast) | reductions | arcs | in_off | wave minima/counts | flags | [align] | max(score block (generic), trace-back block)
-  size_t lds_dp = 16 * S + (fast ? 8 * K2_FB * PERmax : 0) + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
-                  std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), (K2_FB + 1) * LBmax) + 64;
+  // trace-back block: fast = five groups of eight layers, one dword per lane and state slot; generic = 33 layers of bytes
+  const size_t tb_bytes = fast ? 5 * (size_t)nthr * NSl * 4 : (K2_FB + 1) * ((S + 15) & ~size_t(15));
+  // cur | nxt | reductions | arcs | in_off | wave minima/counts | flags | [align] | max(score block (generic), trace-back block)
+  size_t lds_dp = 16 * S + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
+                  std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), tb_bytes) + 64;
   size_t HB = std::max<size_t>(2 * S, 1000);
   size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
   if (lds_dp > 160 * 1024 || lds_f > 160 * 1024)
