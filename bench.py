@@ -74,7 +74,9 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
             orc.acc_stats_ali(om, model.id2pdf, f, r["ali"], oa)
         return f.shape[0]
 
-    # (A) one thread: the reference's execution model (its scripts loop over utterances in Python)
+    # (A) one thread: the reference's execution model (its scripts loop over utterances in Python), built with the
+    # reference's default Release flags (-O3, no -march: BASELINE.md section 3 (i))
+    orc.use("o3")
     oa = orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids)
     frames1 = n1 = 0
     t0 = time.perf_counter()
@@ -84,6 +86,8 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     dt1 = time.perf_counter() - t0
     # (B) utterance-parallel over the host cores (ctypes releases the GIL inside the C oracle), one
     # private accumulator set per thread -- the fairest CPU figure the same code can give
+    # built -O3 -march=native (best-effort CPU)
+    orc.use("native")
     nthr = max(1, min(os.cpu_count() or 1, 32))
     accs = [orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids) for _ in range(nthr)]
     nxt = [n1]
@@ -109,13 +113,15 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
             done[0] += fr
             done[1] += nn
     dtb = time.perf_counter() - tb
+    orc.use(None)
     par = done[0] / dtb if done[1] else 0.0
     one_thr = frames1 / dt1
     best, cores = (par, nthr) if par > one_thr else (one_thr, 1)
     return {"value": best, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread_value": one_thr,
-            "sample": f"oracle/khg_oracle.c (gcc -O2): FasterDecoder + GMM decodable + acc-stats per utterance of rank 0's shard; "
-                      f"1 thread: first {n1} utterances ({frames1} frames) in {dt1:.1f}s; {nthr} threads (utterance-parallel, "
-                      f"private accumulators): next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
+            "sample": f"oracle/khg_oracle.c: FasterDecoder + GMM decodable + acc-stats per utterance of rank 0's shard; "
+                      f"1 thread (gcc -O3, the reference's default flags): first {n1} utterances ({frames1} frames) in {dt1:.1f}s; "
+                      f"{nthr} threads (gcc -O3 -march=native, utterance-parallel, private accumulators): next {done[1]} "
+                      f"utterances ({done[0]} frames) in {dtb:.1f}s"}
 
 
 def main():

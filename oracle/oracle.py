@@ -60,18 +60,44 @@ class OracleError(RuntimeError):
 
 
 _lib = None
+_variants = {}
+
+
+def _open(path):
+    l = C.CDLL(path)
+    l.orc_logsumexp.restype = C.c_float
+    l.orc_softmax.restype = C.c_float
+    l.orc_ml_objective.restype = C.c_float
+    l.orc_augment_gmm_flags.restype = C.c_uint16
+    l.orc_augment_gmm_flags.argtypes = [C.c_uint16]
+    return l
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB)
-        _lib.orc_logsumexp.restype = C.c_float
-        _lib.orc_softmax.restype = C.c_float
-        _lib.orc_ml_objective.restype = C.c_float
-        _lib.orc_augment_gmm_flags.restype = C.c_uint16
-        _lib.orc_augment_gmm_flags.argtypes = [C.c_uint16]
+        _lib = _variants[None] = _open(_LIB)
+    return _lib
+
+
+def use(variant=None):
+    """Switch every wrapper in this module to another BUILD of the same source (bench.py's cpu_baseline):
+    None = the checker (-O2), "o3" = -O3 without -march (the reference's default Release flags), "native" =
+    -O3 -march=native (best-effort CPU).  Built on first use; not thread-safe, call it between timed phases."""
+    global _lib
+    if variant not in _variants:
+        if variant is None:
+            build()
+            _variants[None] = _open(_LIB)
+        else:
+            name = f"libkhg_oracle_{variant}.so"
+            # -march=native must be compiled on the machine that runs it (a copy built elsewhere travels with the
+            # repository snapshot and may use instructions this CPU lacks): always rebuild that one
+            cmd = ["make", "-C", _HERE] + (["-B"] if variant == "native" else []) + [name]
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+            _variants[variant] = _open(os.path.join(_HERE, name))
+    _lib = _variants[variant]
     return _lib
 
 
