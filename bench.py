@@ -221,6 +221,8 @@ def main():
     ev_a = torch.cuda.Event()
     ev_b = torch.cuda.Event()
 
+    ar_events = []
+
     def step():
         accs.zero()                                   # on stream 0
         ev_a.record(streams[0])
@@ -234,11 +236,16 @@ def main():
         for st in streams[1:]:
             ev_b.record(st); streams[0].wait_event(ev_b)
         if dist_on:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(streams[0])
             dist.all_reduce(acc_t)                    # torch's current stream is stream 0
+            e1.record(streams[0])
+            ar_events.append((e0, e1))
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    ar_events.clear()
     for c in ctxs:
         c.sync()                                      # also surfaces deferred kernel errors
         c.set_timing(True)
@@ -343,6 +350,8 @@ def main():
                                  "executed TFLOP/s = achieved x executed_cell_fraction",
                          "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
+            "allreduce_ms_per_step": (sum(a_.elapsed_time(b_) for a_, b_ in ar_events) / max(len(ar_events), 1)) if ar_events else None,
+            "allreduce_bytes": int(accs.size) * 8 if dist_on else None,
             "m_step": m_step,
             "check": {"acc_total_frames": res["total_frames"] , "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},

@@ -41,3 +41,4 @@ def test_bench_collective_path_in_a_one_rank_group():
     d = _run({"KHG_BENCH_FORCE_DIST": "1"}, "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["value"] > 1e6 and d["cpu_baseline"] is None
     assert d["check"]["acc_total_frames"] == d["config"]["frames_per_step"]      # the all-reduce of one rank is the identity
+    assert d["allreduce_ms_per_step"] is not None and d["allreduce_ms_per_step"] >= 0.0 and d["allreduce_bytes"] > 0
