@@ -1087,13 +1087,14 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
     {
       KernelTimer kt(ctx, "k3_bucket");
-      hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
-      hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
       const char* bk = getenv("KHG_K3_BUCKET");      // "atomic": cursor-bump scatter (bucket order depends on the atomics)
       if ((bk && strcmp(bk, "atomic") == 0) || u->N >= (int64_t)INT_MAX) {
+        hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
       } else {
-        // stable sort of (pdf, frame) pairs: frames of a pdf stay in frame order
+        // stable sort of (pdf, frame) pairs: frames of a pdf stay in frame order; the bucket boundaries are read
+        // off the sorted keys
         int bits = 1;
         while ((1 << bits) <= m->P) ++bits;            // keys are 0..P
         if (!u->sort_keys_d) {
@@ -1113,6 +1114,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
         hipLaunchKernelGGL(k3_sort_keys, dim3(gb), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
                                                   reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+        hipLaunchKernelGGL(k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
       }
     }
     int maxG = 0;
