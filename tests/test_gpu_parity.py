@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from helpers import build, exact_loglikes, oracle_graph, utt_feats
+from kaldi_hmm_gmm_amd import synth
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -293,6 +294,42 @@ def test_acc_stats_reproducible_bit_for_bit(ctx, monkeypatch):
                                         [st["total_frames"], st["total_log_like"]]]))
         assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), ny
         assert runs[0][-2] == pytest.approx(0.3 * ut.frame_off[-1], rel=1e-6)
+
+
+def test_align_very_short_utterances(ctx):
+    """T = 3 .. ~12 frames (one to three phones, almost no self-loops): the packed back-pointer groups of eight layers
+    are partial, the score blocks are mostly padding, and utterances one frame too short for their graph must fail
+    exactly like the reference."""
+    m, gc, om, ut, cost = build(30, 4, 13, n_utt=40, seed=77, min_phones=1, max_phones=3)
+    ut = synth.make_utts(m, 40, seed=78, min_phones=1, max_phones=3, leave_prob=0.97)
+    T = np.diff(ut.frame_off)
+    assert T.min() <= 4 and T.max() <= 16
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm, reachable_only=True)
+    res = us.align(tm, beam=200.0, acoustic_scale=0.1)
+    for u in range(us.n_utt):
+        want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1)
+        assert (int(res["status"][u]) & 1) == (want["status"] & 1)
+        if not want["status"] & 1:
+            assert (res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]] == want["ali"]).all()
+    # drop the last frame of every utterance: the ones that had exactly one frame per state can no longer reach the end
+    fo = ut.frame_off - np.arange(len(ut.frame_off))
+    keep = np.ones(ut.frame_off[-1], bool)
+    keep[ut.frame_off[1:] - 1] = False
+    import dataclasses
+    ut2 = dataclasses.replace(ut, frame_off=fo.astype(np.int64), feats=ut.feats[keep])
+    dm2, tm2, us2 = _device(ctx, m, gc, ut2, cost)
+    us2.loglikes(dm2, reachable_only=True)
+    res2 = us2.align(tm2, beam=200.0, acoustic_scale=0.1)
+    nerr = 0
+    for u in range(us2.n_utt):
+        f = utt_feats(ut2, u)
+        want = orc.align_utterance(oracle_graph(ut2, u, cost), om, m.id2pdf, f, acoustic_scale=0.1)
+        assert (int(res2["status"][u]) & 1) == (want["status"] & 1), u
+        nerr += want["status"] & 1
+        if not want["status"] & 1:
+            assert (res2["ali"][ut2.frame_off[u]: ut2.frame_off[u + 1]] == want["ali"]).all()
+    assert nerr > 0
 
 
 def _first_frames(g, u, id2pdf, pdfs):
