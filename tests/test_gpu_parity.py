@@ -332,6 +332,24 @@ def test_align_very_short_utterances(ctx):
     assert nerr > 0
 
 
+def test_align_long_utterances_many_waves(ctx):
+    """600-900 states (10-15 waves per utterance), thousands of frames: wave trimming per utterance, the 32-layer
+    certificate folds and the back-pointer groups across many waves."""
+    m, gc, om, ut, cost = build(90, 3, 13, n_utt=4, seed=31, min_phones=200, max_phones=300)
+    S = np.diff(ut.graphs["state_off"])
+    assert S.max() > 640 and np.diff(ut.frame_off).max() > 2000
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm, reachable_only=True)
+    for beam, retry in ((200.0, 0.0), (8.0, 40.0)):
+        res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1)
+        for u in range(us.n_utt):
+            want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1, beam=beam,
+                                       retry_beam=retry)
+            assert want["status"] & 1 == 0 and int(res["status"][u]) & 1 == 0
+            assert (res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]] == want["ali"]).all()
+            assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
+
+
 def _first_frames(g, u, id2pdf, pdfs):
     """Fewest emitting arcs before an arc with each listed pdf can be taken (0-1 BFS from the start state)."""
     from collections import deque
