@@ -350,6 +350,29 @@ def test_align_long_utterances_many_waves(ctx):
             assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
 
 
+def test_align_graphs_beyond_1024_states(ctx):
+    """More than 1024 states: two states per thread on K2's register-resident path.  (The order-faithful fallback keeps
+    its token tables in LDS, which bounds supported graphs at roughly 1500 states: larger ones are refused loudly.)"""
+    from kaldi_hmm_gmm_amd import KhgError
+
+    m, gc, om, ut, cost = build(90, 2, 13, n_utt=2, seed=400, min_phones=400, max_phones=420)
+    S = int(np.diff(ut.graphs["state_off"]).max())
+    assert 1024 < S <= 2048
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm, reachable_only=True)
+    res = us.align(tm, beam=200.0, acoustic_scale=0.1)
+    for u in range(us.n_utt):
+        want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1)
+        assert want["status"] & 1 == 0 and int(res["status"][u]) & 1 == 0
+        assert (res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]] == want["ali"]).all()
+        assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
+    m, gc, om, ut, cost = build(90, 2, 13, n_utt=1, seed=900, min_phones=900, max_phones=910)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm, reachable_only=True)
+    with pytest.raises(KhgError, match="too large"):
+        us.align(tm, beam=200.0, acoustic_scale=0.1)
+
+
 def _first_frames(g, u, id2pdf, pdfs):
     """Fewest emitting arcs before an arc with each listed pdf can be taken (0-1 BFS from the start state)."""
     from collections import deque
