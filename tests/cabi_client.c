@@ -3,7 +3,7 @@
  *   khg_compute_gconsts -> khg_model_create / khg_tm_create / khg_utts_create -> khg_loglikes_reachable ->
  *   khg_align -> khg_acc_stats -> khg_model_mle_update -> khg_model_download
  * checked against the CPU oracle (oracle/khg_oracle.h; test infrastructure): alignments bit-exact, statistics
- * rtol 2e-5, M-step parameters bit-exact / gconsts <= 2 ulp on the device's own statistics.
+ * rtol 2e-5, M-step parameters bit-exact / gconsts <= 4 ulp on the device's own statistics.
  * `cabi_client --no-gpu` runs only the host-side entry points and checks that khg_ctx_create fails loudly.
  * Built by __graft_entry__.build() with gcc -std=c11 -Wall -Wextra -Werror -pedantic. */
 #include <math.h>
@@ -203,7 +203,7 @@ int main(int argc, char **argv) {
     REQUIRE(memcmp(pmiv, nmiv + (size_t)new_off[p] * D, sizeof(float) * (size_t)Gp * D) == 0);
     for (int g = 0; g < Gp; ++g) { const double e = ulps(pgc[g], ngc[new_off[p] + g]); if (e > worst) worst = e; }
   }
-  REQUIRE(worst <= 2.0 && tot_removed == rm && newG == sumG - rm);
+  REQUIRE(worst <= 4.0 && tot_removed == rm && newG == sumG - rm);
   REQUIRE(fabs((double)cnt - (double)nfr) <= 1e-4 * (double)nfr);
   free(blk);
   CHECK(khg_accs_destroy(acc)); CHECK(khg_utts_destroy(us)); CHECK(khg_tm_destroy(tm)); CHECK(khg_model_destroy(m));

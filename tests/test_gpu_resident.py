@@ -63,14 +63,14 @@ def test_resident_em_matches_per_call_scripts(ctx):
     likes = []
     for it, target in enumerate(mix):
         if it > 0:
-            # boost: device vs scripts/gmm_boost_silence.py on a host copy (gconsts through logf: <= 2 ulps)
+            # boost: device vs scripts/gmm_boost_silence.py on a host copy (gconsts through logf: <= 4 ulps)
             am_h = _clone(em.sync_host())
             khg.gmm_boost_silence(am_h, tm_b, [ex.SIL], boost=1.25)
             em.boost_silence([ex.SIL], boost=1.25)
             am_d = _clone(em.sync_host())
             _, gc_h, w_h, _, _ = am_h.flat()
             _, gc_d, w_d, _, _ = am_d.flat()
-            assert np.array_equal(w_h, w_d) and (np.abs(gc_h - gc_d) <= 2 * np.spacing(np.abs(gc_h))).all()
+            assert np.array_equal(w_h, w_d) and (np.abs(gc_h - gc_d) <= 4 * np.spacing(np.abs(gc_h))).all()
             # align: the per-call script on the SAME parameters gives the same alignments, counters and likelihood
             r = em.align(cfg)
             ra = khg.gmm_align_compiled_batch(am_d, tm_b, names, graphs, feats, cfg, acoustic_scale=0.1, transition_scale=1.0,
