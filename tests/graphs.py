@@ -3,7 +3,7 @@ branches, epsilon-input arcs with word labels, unreachable finals."""
 import numpy as np
 
 
-def random_graph(rng, num_tids, n_main=8, p_branch=0.3, p_eps=0.2, with_final=True):
+def random_graph(rng, num_tids, n_main=8, p_branch=0.3, p_eps=0.2, with_final=True, p_long=0.0):
     """Left-to-right graph over states 0..n: every state gets a self-loop (tid) and a forward arc;
     some get a skip/branch arc, some an epsilon-input arc carrying a word label."""
     arcs = []   # (src, ilabel, olabel, weight, dst)
@@ -15,6 +15,9 @@ def random_graph(rng, num_tids, n_main=8, p_branch=0.3, p_eps=0.2, with_final=Tr
             arcs.append((s, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s))      # self loop
         if s + 2 <= n and rng.random() < p_branch:
             arcs.append((s, int(rng.integers(1, num_tids + 1)), 0, float(rng.random() + 0.5), s + 2))
+        for hop in (3, 4):                                   # longer skips: in-degrees of 4..6 (K2's <.,6,true> instantiation)
+            if p_long and s + hop <= n and rng.random() < p_long:
+                arcs.append((s, int(rng.integers(1, num_tids + 1)), 0, float(rng.random() + 0.5), s + hop))
         if s + 1 <= n and rng.random() < p_eps:
             arcs.append((s, 0, int(rng.integers(1, 50)), float(rng.random() * 0.3), s + 1))     # eps:word
     arcs.append((n, int(rng.integers(1, num_tids + 1)), 0, 0.1, n))

@@ -22,14 +22,14 @@ while time.time() - t0 < budget:
     m = synth.make_model(P, G, D, seed=seed)
     gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
     U = int(rng.integers(1, 14))
-    p_eps = float(rng.choice([0.0, 0.2, 0.6])); p_br = float(rng.choice([0.0, 0.3, 0.8]))
+    p_eps = float(rng.choice([0.0, 0.0, 0.2, 0.6])); p_br = float(rng.choice([0.0, 0.3, 0.8])); p_long = float(rng.choice([0.0, 0.5, 0.9]))
     graphs = []
     for _ in range(U):
         r = rng.random()
         if r < 0.04:
             graphs.append(EMPTY)
         else:
-            graphs.append(random_graph(rng, m.num_tids, n_main=int(rng.integers(1, 40)), p_branch=p_br, p_eps=p_eps, with_final=r > 0.1))
+            graphs.append(random_graph(rng, m.num_tids, n_main=int(rng.integers(1, 40)), p_branch=p_br, p_eps=p_eps, with_final=r > 0.1, p_long=p_long))
     if all(g is EMPTY for g in graphs):       # a set without any state is a features-only set by the C-ABI's contract
         graphs[0] = random_graph(rng, m.num_tids, n_main=3)
     T = [int(rng.integers(max(1, len(g["final"]) - 2), len(g["final"]) + 40)) for g in graphs]
@@ -50,7 +50,7 @@ while time.time() - t0 < budget:
     kw = {}
     if rng.random() < 0.25:
         kw = {"max_active": int(rng.choice([2, 5, 30])), "min_active": int(rng.choice([0, 1]))}
-    tag = f"P{P} G{G} D{D} U{U} eps{p_eps} br{p_br} beam{beam}/{retry} scale{scale} {kw} seed{seed}"
+    tag = f"P{P} G{G} D{D} U{U} eps{p_eps} br{p_br} long{p_long} beam{beam}/{retry} scale{scale} {kw} seed{seed}"
     res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=scale, **kw)
     for u, g in enumerate(graphs):
         og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
