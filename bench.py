@@ -59,8 +59,6 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     AlignUtteranceWrapper + acc-stats per utterance, one thread -- the reference's execution model."""
     from oracle import oracle as orc
 
-    import concurrent.futures as cf
-
     om = orc.OModel(model.gauss_off, gc, model.means_invvars, model.inv_vars)
     g = dict(ut.graphs)
     g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[g["ilabel"]], g["weight"]).astype(np.float32)
@@ -84,35 +82,37 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
         frames1 += one(n1, oa)
         n1 += 1
     dt1 = time.perf_counter() - t0
-    # (B) utterance-parallel over the host cores (ctypes releases the GIL inside the C oracle), one
-    # private accumulator set per thread -- the fairest CPU figure the same code can give
-    # built -O3 -march=native (best-effort CPU)
+    # (B) utterance-parallel over ALL host cores inside the C oracle (orc_em_pass_mt: POSIX threads, a private accumulator
+    # set per thread, the same two calls per utterance), built -O3 -march=native
     orc.use("native")
-    nthr = max(1, min(os.cpu_count() or 1, 32))
-    accs = [orc.OAccs(int(model.gauss_off[-1]), model.dim, model.num_tids) for _ in range(nthr)]
-    nxt = [n1]
-    import threading
-    lock = threading.Lock()
-    done = [0, 0]
-    tb = time.perf_counter()
-
-    def worker(k):
-        fr = nn = 0
-        while time.perf_counter() - tb < budget_s / 2:
-            with lock:
-                u = nxt[0]
-                nxt[0] += 1
-            if u >= nmax:
-                break
-            fr += one(u, accs[k])
-            nn += 1
-        return fr, nn
-
-    with cf.ThreadPoolExecutor(nthr) as ex:
-        for fr, nn in ex.map(worker, range(nthr)):
-            done[0] += fr
-            done[1] += nn
-    dtb = time.perf_counter() - tb
+    # bounded by memory: every thread owns an accumulator set (sumG * (2 D + 1) doubles)
+    acc_bytes = int(model.gauss_off[-1]) * (2 * model.dim + 1) * 8
+    try:
+        import psutil
+        mem_cap = int(0.25 * psutil.virtual_memory().available // max(acc_bytes, 1))
+    except Exception:
+        mem_cap = 32
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = ncpu                       # a container may see every core of the host but be allowed only a few of them
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:               # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            if q != "max":
+                quota = max(1, -(-int(q) // int(per)))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:   # cgroup v1
+                q, per = int(f1.read()), int(f2.read())
+                if q > 0:
+                    quota = max(1, -(-q // per))
+        except Exception:
+            pass
+    nthr = max(1, min(ncpu, quota, mem_cap, 512))
+    if os.environ.get("KHG_BENCH_CPU_THREADS"):
+        nthr = max(1, int(os.environ["KHG_BENCH_CPU_THREADS"]))
+    fr, nn, failed, dtb = orc.em_pass_mt(om, model.id2pdf, g, ut.frame_off, feats_host["feats"], first_utt=n1, n_utt=max(nmax - n1, 0),
+                                         num_threads=nthr, budget_seconds=budget_s / 2, acoustic_scale=0.1)
+    done = [fr, nn]
     orc.use(None)
     par = done[0] / dtb if done[1] else 0.0
     one_thr = frames1 / dt1
@@ -120,8 +120,9 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     return {"value": best, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread_value": one_thr,
             "sample": f"oracle/khg_oracle.c: FasterDecoder + GMM decodable + acc-stats per utterance of rank 0's shard; "
                       f"1 thread (gcc -O3, the reference's default flags): first {n1} utterances ({frames1} frames) in {dt1:.1f}s; "
-                      f"{nthr} threads (gcc -O3 -march=native, utterance-parallel, private accumulators): next {done[1]} "
-                      f"utterances ({done[0]} frames) in {dtb:.1f}s"}
+                      f"{nthr} POSIX threads inside the C oracle ({ncpu} logical CPUs visible, CPU quota {quota}; gcc -O3 -march=native, "
+                      f"utterance-parallel, private accumulators): "
+                      f"next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
 
 
 def main():
@@ -357,7 +358,7 @@ def main():
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
         }
         if not args.no_cpu_baseline and world == 1:
-            ncpu = min(n_local, 16384)
+            ncpu = min(n_local, 40000)     # enough work for a few seconds of every host core
             fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)
         else:

@@ -11,6 +11,7 @@
  *
  * Build: gcc -O2 -ffp-contract=off (no -ffast-math: float/double rounding points matter).
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime / pthreads for orc_em_pass_mt under -std=c11 */
 #include "khg_oracle.h"
 
 #include <float.h>
@@ -1084,4 +1085,129 @@ int orc_transition_mle_update(int32_t num_tstates, const int32_t *state2id,
     }
   }
   return ORC_OK;
+}
+
+/* ---- utterance-parallel driver for bench.py's cpu_baseline (variant B) ----
+ * Not a reference function: the reference is single-threaded.  N POSIX threads take utterances from a shared counter and
+ * run exactly what the one-thread baseline runs per utterance (orc_align_utterance, then orc_acc_stats_ali on success),
+ * each into its own accumulator set, until the utterances run out or `budget_seconds` have passed.  Graphs arrive as
+ * the concatenated CSR of khg_utts_create (weights already include the transition costs). */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+  const orc_align_config *cfg; float acoustic_scale;
+  const orc_model *m; const int32_t *id2pdf; int32_t num_tids;
+  int32_t first_utt, n_utt;
+  const int64_t *frame_off, *state_off, *arc_off;
+  const int32_t *start, *ilabel, *olabel, *nextstate;
+  const float *weight, *final, *feats;
+  double budget_seconds;
+  struct timespec t0;
+  volatile int32_t next;       /* shared utterance cursor */
+  pthread_mutex_t mu;
+  pthread_cond_t cv;           /* start gate: accumulators are allocated and touched on every thread before the clock starts */
+  int32_t ready_count, go;
+  int64_t frames_done; int32_t utts_done; int32_t failed;
+  double t_end;                /* when the last thread finished its last utterance */
+} orc_mt_job;
+
+static double mt_elapsed(const struct timespec *t0) {
+  struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)(t.tv_sec - t0->tv_sec) + 1e-9 * (double)(t.tv_nsec - t0->tv_nsec);
+}
+
+static void *mt_worker(void *arg) {
+  orc_mt_job *j = (orc_mt_job *)arg;
+  const orc_model *m = j->m;
+  const int64_t sumG = m->gauss_off[m->num_pdfs];
+  orc_accs acc;
+  acc.occ = (double *)calloc((size_t)sumG, sizeof(double));
+  acc.mean_acc = (double *)calloc((size_t)sumG * m->dim, sizeof(double));
+  acc.var_acc = (double *)calloc((size_t)sumG * m->dim, sizeof(double));
+  acc.trans_acc = (double *)calloc((size_t)j->num_tids + 1, sizeof(double));
+  acc.total_frames = acc.total_log_like = 0.0;
+  int64_t frames = 0; int32_t utts = 0, failed = 0;
+  const int have = acc.occ && acc.mean_acc && acc.var_acc && acc.trans_acc;
+  if (have) {   /* touch every page now: a long-running job pays its page faults once, a few-second sample would be all faults */
+    memset(acc.occ, 0, sizeof(double) * (size_t)sumG);
+    memset(acc.mean_acc, 0, sizeof(double) * (size_t)sumG * m->dim);
+    memset(acc.var_acc, 0, sizeof(double) * (size_t)sumG * m->dim);
+  }
+  pthread_mutex_lock(&j->mu);
+  ++j->ready_count;
+  pthread_cond_broadcast(&j->cv);
+  while (!j->go) pthread_cond_wait(&j->cv, &j->mu);
+  pthread_mutex_unlock(&j->mu);
+  if (have) {
+    for (;;) {
+      if (mt_elapsed(&j->t0) >= j->budget_seconds) break;
+      pthread_mutex_lock(&j->mu);
+      const int32_t u = j->next < j->n_utt ? j->first_utt + j->next++ : -1;
+      pthread_mutex_unlock(&j->mu);
+      if (u < 0) break;
+      const int64_t s0 = j->state_off[u], S = j->state_off[u + 1] - s0, a0 = j->arc_off[s0];
+      const int32_t T = (int32_t)(j->frame_off[u + 1] - j->frame_off[u]);
+      int32_t *loc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+      int32_t *ali = (int32_t *)malloc(sizeof(int32_t) * (size_t)(T > 0 ? T : 1));
+      int32_t *words = (int32_t *)malloc(sizeof(int32_t) * (size_t)(T + S + 8));
+      if (!loc || !ali || !words) { free(loc); free(ali); free(words); break; }
+      for (int64_t s = 0; s <= S; ++s) loc[s] = (int32_t)(j->arc_off[s0 + s] - a0);
+      orc_graph g = {(int32_t)S, j->start[u], loc, j->ilabel + a0, j->olabel + a0, j->weight + a0, j->nextstate + a0, j->final + s0};
+      int32_t nw = 0, status = 0; float like = 0.0f;
+      const float *x = j->feats + j->frame_off[u] * m->dim;
+      int rc = orc_align_utterance(j->cfg, j->acoustic_scale, &g, m, j->id2pdf, j->num_tids, T, x, ali, words, (int32_t)(T + S + 8), &nw,
+                                   &like, &status, NULL);
+      if (rc == ORC_OK && (status & ORC_ALIGN_ERROR) == 0) {
+        double ll = 0.0;
+        orc_acc_stats_ali(m, j->id2pdf, j->num_tids, T, x, ali, 1.0f, &acc, &ll);
+      } else {
+        ++failed;
+      }
+      frames += T; ++utts;
+      free(loc); free(ali); free(words);
+    }
+  }
+  const double t_end = mt_elapsed(&j->t0);
+  free(acc.occ); free(acc.mean_acc); free(acc.var_acc); free(acc.trans_acc);
+  pthread_mutex_lock(&j->mu);
+  j->frames_done += frames; j->utts_done += utts; j->failed += failed;
+  if (t_end > j->t_end) j->t_end = t_end;
+  pthread_mutex_unlock(&j->mu);
+  return NULL;
+}
+
+int orc_em_pass_mt(const orc_align_config *cfg, float acoustic_scale, const orc_model *m, const int32_t *id2pdf, int32_t num_tids,
+                   int32_t first_utt, int32_t n_utt, const int64_t *frame_off, const float *feats, const int64_t *state_off,
+                   const int32_t *start, const int64_t *arc_off, const int32_t *ilabel, const int32_t *olabel,
+                   const float *weight, const int32_t *nextstate, const float *final, int32_t num_threads,
+                   double budget_seconds, int64_t *frames_done, int32_t *utts_done, int32_t *failed, double *seconds) {
+  if (num_threads < 1 || n_utt < 0) return ORC_ERR_ARG;
+  orc_mt_job j;
+  memset(&j, 0, sizeof(j));
+  j.cfg = cfg; j.acoustic_scale = acoustic_scale; j.m = m; j.id2pdf = id2pdf; j.num_tids = num_tids;
+  j.first_utt = first_utt; j.n_utt = n_utt; j.frame_off = frame_off; j.state_off = state_off; j.arc_off = arc_off;
+  j.start = start; j.ilabel = ilabel; j.olabel = olabel; j.nextstate = nextstate; j.weight = weight; j.final = final; j.feats = feats;
+  j.budget_seconds = budget_seconds;
+  pthread_mutex_init(&j.mu, NULL);
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)num_threads);
+  if (!th) return ORC_ERR_NOMEM;
+  pthread_cond_init(&j.cv, NULL);
+  int started = 0;
+  for (int i = 0; i < num_threads; ++i) { if (pthread_create(&th[i], NULL, mt_worker, &j) != 0) break; ++started; }
+  pthread_mutex_lock(&j.mu);
+  while (j.ready_count < started) pthread_cond_wait(&j.cv, &j.mu);
+  clock_gettime(CLOCK_MONOTONIC, &j.t0);       /* the clock starts when every thread is ready */
+  j.go = 1;
+  pthread_cond_broadcast(&j.cv);
+  pthread_mutex_unlock(&j.mu);
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  pthread_cond_destroy(&j.cv);
+  if (seconds) *seconds = j.t_end;
+  free(th);
+  pthread_mutex_destroy(&j.mu);
+  if (frames_done) *frames_done = j.frames_done;
+  if (utts_done) *utts_done = j.utts_done;
+  if (failed) *failed = j.failed;
+  return started > 0 ? ORC_OK : ORC_ERR_NOMEM;
 }

@@ -200,6 +200,18 @@ int orc_transition_mle_update(int32_t num_tstates, const int32_t *state2id,
                               float mincount, float *log_probs, float *non_self_loop_log_probs,
                               float *objf_impr, float *count);
 
+/* bench.py's cpu_baseline, variant B: `num_threads` POSIX threads run orc_align_utterance +
+ * orc_acc_stats_ali per utterance (private accumulators) over utterances [first_utt, first_utt + n_utt) of a set in
+ * the C-ABI's concatenated CSR layout, for at most `budget_seconds`.  Not a reference function (the reference is
+ * single-threaded). */
+int orc_em_pass_mt(const orc_align_config *cfg, float acoustic_scale, const orc_model *m,
+                   const int32_t *id2pdf, int32_t num_tids, int32_t first_utt, int32_t n_utt,
+                   const int64_t *frame_off, const float *feats, const int64_t *state_off,
+                   const int32_t *start, const int64_t *arc_off, const int32_t *ilabel,
+                   const int32_t *olabel, const float *weight, const int32_t *nextstate,
+                   const float *final, int32_t num_threads, double budget_seconds,
+                   int64_t *frames_done, int32_t *utts_done, int32_t *failed, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,6 +301,31 @@ def acc_stats_ali(m: OModel, id2pdf, feats, ali, accs: OAccs, weight=1.0):
     return ll.value
 
 
+def em_pass_mt(m: "OModel", id2pdf, graphs: dict, frame_off, feats, first_utt=0, n_utt=None, num_threads=1, budget_seconds=1e9,
+               acoustic_scale=1.0, beam=200.0, retry_beam=0.0, **kw):
+    """orc_em_pass_mt: align + acc-stats per utterance on `num_threads` POSIX threads (bench.py's cpu_baseline, variant B).
+    `graphs` is the concatenated CSR dict of the utterance set (weights already carrying the transition costs).
+    -> (frames_done, utterances_done, failed, seconds)"""
+    id2pdf = np.ascontiguousarray(id2pdf, np.int32)
+    fo = np.ascontiguousarray(frame_off, np.int64)
+    x = np.ascontiguousarray(feats, f32)
+    g = {k: np.ascontiguousarray(graphs[k], dt) for k, dt in (("state_off", np.int64), ("start", np.int32), ("arc_off", np.int64),
+                                                                ("ilabel", np.int32), ("olabel", np.int32), ("weight", f32),
+                                                                ("nextstate", np.int32), ("final", f32))}
+    n_all = fo.shape[0] - 1
+    n_utt = n_all - first_utt if n_utt is None else min(n_utt, n_all - first_utt)
+    cfg = _cfg(beam, retry_beam, **kw)
+    frames = C.c_int64(); utts = C.c_int32(); failed = C.c_int32(); secs = C.c_double()
+    _chk(lib().orc_em_pass_mt(C.byref(cfg), C.c_float(acoustic_scale), C.byref(m.c), _p(id2pdf, C.c_int32), id2pdf.shape[0] - 1,
+                              C.c_int32(first_utt), C.c_int32(max(n_utt, 0)), _p(fo, C.c_int64), _p(x, C.c_float),
+                              _p(g["state_off"], C.c_int64), _p(g["start"], C.c_int32), _p(g["arc_off"], C.c_int64),
+                              _p(g["ilabel"], C.c_int32), _p(g["olabel"], C.c_int32), _p(g["weight"], C.c_float),
+                              _p(g["nextstate"], C.c_int32), _p(g["final"], C.c_float), C.c_int32(num_threads),
+                              C.c_double(budget_seconds), C.byref(frames), C.byref(utts), C.byref(failed), C.byref(secs)),
+         "em_pass_mt")
+    return frames.value, utts.value, failed.value, secs.value
+
+
 def mle_diag_gmm_update(weights, means_invvars, inv_vars, occ, mean_acc, var_acc, acc_flags=0xF, flags=0x7,
                         min_gaussian_weight=1e-5, min_gaussian_occupancy=10.0, min_variance=1e-3, remove=True):
     w = np.array(weights, f32, copy=True); miv = np.array(means_invvars, f32, copy=True)

@@ -118,3 +118,20 @@ def test_gconst_edge_cases():
     iv[1, 0] = -1.0
     with pytest.raises(orc.OracleError):
         orc.compute_gconsts(w, iv, miv)
+
+
+def test_threaded_em_pass_driver_counts_every_utterance():
+    """orc_em_pass_mt (bench.py's cpu_baseline, variant B): same per-utterance calls on POSIX threads."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from helpers import build
+    m, gc, om, ut, cost = build(12, 3, 6, n_utt=9, seed=3, max_phones=4)
+    g = dict(ut.graphs)
+    g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[g["ilabel"]], g["weight"]).astype(np.float32)
+    for nthr in (1, 3):
+        frames, utts, failed, secs = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, num_threads=nthr, acoustic_scale=0.1)
+        assert frames == ut.frame_off[-1] and utts == 9 and failed == 0 and secs > 0
+    frames, utts, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, first_utt=4, n_utt=3, num_threads=2, acoustic_scale=0.1)
+    assert utts == 3 and frames == ut.frame_off[7] - ut.frame_off[4]
+    frames, utts, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, num_threads=2, budget_seconds=0.0, acoustic_scale=0.1)
+    assert utts == 0 and frames == 0
