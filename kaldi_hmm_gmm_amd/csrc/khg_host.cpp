@@ -4,7 +4,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
-#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -54,25 +53,6 @@ float MlObjective(int G, int D, const float* gc, const float* miv, const float* 
     obj -= 0.5 * s;
   }
   return obj;
-}
-
-// CPUs this process may actually use: a container often sees every core of the host (hardware_concurrency) but is
-// granted only a few of them (cgroup CPU quota); more threads than that only add context switches.
-int UsableCpus() {
-  int n = (int)std::thread::hardware_concurrency();
-  if (n < 1) n = 1;
-  long long q = -1, per = 0;
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2: "<quota> <period>" or "max <period>"
-    char buf[64];
-    if (fscanf(f, "%63s %lld", buf, &per) == 2 && strcmp(buf, "max") != 0) q = atoll(buf);
-    fclose(f);
-  } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
-    if (fscanf(f1, "%lld", &q) != 1) q = -1;
-    fclose(f1);
-    if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 0; fclose(f2); }
-  }
-  if (q > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (q + per - 1) / per));
-  return n;
 }
 
 struct UpdateResult { float obj_change = 0, count = 0; int floored_elems = 0, floored_gauss = 0, removed = 0; };
@@ -191,7 +171,7 @@ extern "C" int khg_mle_am_diag_gmm_update(const khg_mle_options* o, int32_t P, i
   std::vector<UpdateResult> res((size_t)P);
   std::vector<int32_t> newG((size_t)P, 0);
   std::vector<uint8_t> bad((size_t)P, 0);
-  int nthr = UsableCpus();
+  int nthr = (int)std::thread::hardware_concurrency();
   if (const char* e = getenv("KHG_HOST_THREADS")) nthr = atoi(e);
   nthr = std::max(1, std::min(nthr, 64));
   if ((int64_t)gauss_off[P] * D < (1 << 16)) nthr = 1;
