@@ -4,8 +4,11 @@
 5000-pdf x 64-Gaussian, 40-dim synthetic workload (configs[3]).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; one rank per GPU (RANK/LOCAL_RANK/
-WORLD_SIZE from the env under torch.distributed.run); rank 0 prints ONE JSON line.
-Strong scaling as configs[3] states it: the 100k-utterance set is SHARDED across the N ranks.
+WORLD_SIZE from the env under torch.distributed.run); rank 0 prints ONE JSON line.  Run from a bare shell
+with --gpus N > 1 it starts the N ranks itself (fresh child processes through torch.distributed.run, before
+anything in this process has touched a GPU) and relays rank 0's line.
+Strong scaling as configs[3] states it: the ONE 100k-utterance set (the N = 1 workload, same seeds, same
+frames) is dealt to the N ranks by total frames (kaldi_hmm_gmm_amd.dist.shard_utterances).
 """
 import argparse
 import json
@@ -36,22 +39,67 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
     ap.add_argument("--seed", type=int, default=20230418)
+    ap.add_argument("--allreduce", choices=["khg", "torch", "khg-f32", "host"], default="khg",
+                    help="C1: khg = khg_accs_allreduce (RCCL called by the library on the kernels' stream); torch = "
+                         "torch.distributed.all_reduce on a view of the block; khg-f32 = the fp32-wire tolerance experiment; "
+                         "host = block summed over gloo on the host (test rig: KHG_BENCH_SHARE_GPU=1 puts every rank on GPU 0, "
+                         "where RCCL refuses to form a communicator)")
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: N fresh child processes, one per GPU, under
+    torch.distributed.run.  This process has imported neither torch nor the library: nothing here has initialised
+    a GPU, and nothing is exec'ed -- the children are ordinary subprocesses whose return code becomes ours."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in r.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(r.returncode if r.returncode else (0 if lines else 3))
+
+
+def csrc_sha():
+    """Identity of the kernels a PMC profile belongs to: sha256 over the library's sources."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kaldi_hmm_gmm_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".inc", ".cpp", ".h")):
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(fn.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(frames_per_launch):
-    """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.json:
-    separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction), valid only for
-    the launch size it was collected at -- bench.py cannot run the profiler on itself."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as fh:
-            pm = json.load(fh)
-        k1 = next(v for k, v in pm["kernels"].items() if k.startswith(("k1p_loglikes", "k1_loglikes")))
-        if abs(pm["frames_per_launch"] / frames_per_launch - 1.0) > 0.02:
-            return None, None
-        return k1["traffic_bytes"], "profiles/r1_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same launch size)"
-    except Exception:
-        return None, None
+    """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json: separate
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction) -- bench.py cannot run the profiler on
+    itself.  Only reported when the profile was taken at this launch size AND on these kernel sources (csrc_sha);
+    otherwise null with the reason."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                pm = json.load(fh)
+            k1 = next(v for k, v in pm["kernels"].items() if k.startswith(("k1p_loglikes", "k1_loglikes", "k1b_loglikes")))
+            rel = os.path.relpath(path, ROOT)
+            if abs(pm["frames_per_launch"] / frames_per_launch - 1.0) > 0.02:
+                return None, f"{rel}: collected at another launch size ({pm['frames_per_launch']} frames)"
+            if pm.get("csrc_sha") != csrc_sha():
+                return None, f"{rel}: collected on other kernel sources (csrc_sha {pm.get('csrc_sha')}, now {csrc_sha()})"
+            return k1["traffic_bytes"], f"{rel} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same launch size, csrc_sha {pm['csrc_sha']})"
+        except Exception:
+            continue
+    return None, "no PMC summary under profiles/"
 
 
 def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
@@ -127,6 +175,8 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     # stdout carries exactly ONE line, the JSON record of rank 0.  RCCL prints a version banner through C stdio on
     # stdout (flushed at exit, i.e. AFTER anything Python printed), torch may warn there too: everything else in
     # the process is pointed at stderr and the record is written to the saved descriptor at the very end.
@@ -140,10 +190,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    share_gpu = os.environ.get("KHG_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local, args.allreduce = 0, "host"
+    backend = "gloo" if args.allreduce == "host" else "nccl"
     torch.cuda.set_device(local)
     # KHG_BENCH_FORCE_DIST=1: run the collective code path (process group, all-reduce of the accumulator block, max /
     # sum of the timings) in a one-rank group -- the only way to exercise it on a one-GPU box
@@ -151,10 +203,11 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         if world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, **kw)
         else:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=0, world_size=1, **kw)
 
     from kaldi_hmm_gmm_amd import Context, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet, synth
     from kaldi_hmm_gmm_amd import _lib
@@ -172,10 +225,25 @@ def main():
                                               _lib.ptr(model.non_self_loop_log_probs, C.c_float),
                                               _lib.ptr(model.id2state, C.c_int32), _lib.ptr(model.is_self_loop, C.c_uint8),
                                               1.0, 0.1, _lib.ptr(cost, C.c_float)))
-    n_local = args.utts // world + (1 if rank < args.utts % world else 0)
-    ut = synth.make_utts(model, n_local, seed=args.seed + 1000 + rank, feats=False)
+    # ONE utterance set, whatever N: every rank builds the whole (feature-less) set from the N = 1 seeds, keeps the
+    # utterances shard_utterances deals it, and draws the one global feature stream storing only its own frames
+    from kaldi_hmm_gmm_amd.dist import make_comm, shard_utterances, take_utterances
+    ut_all = synth.make_utts(model, args.utts, seed=args.seed + 1000, feats=False)
     dev = torch.device("cuda", local)
-    feats = synth.sample_feats_torch(model, ut.frame_pdf, args.seed + 2000 + rank, dev)
+    if world > 1:
+        mine = shard_utterances(np.diff(ut_all.frame_off), world)[rank]
+        fo_l, g_l, fr_l = take_utterances(ut_all.frame_off, ut_all.graphs, mine)
+        keep = np.zeros(int(ut_all.frame_off[-1]), bool)
+        keep[fr_l] = True
+        feats = synth.sample_feats_torch(model, ut_all.frame_pdf, args.seed + 2000, dev, keep=keep)
+        ut = synth.SynthUtts(fo_l, None, ut_all.ref_ali[fr_l], ut_all.frame_pdf[fr_l], g_l, ut_all.num_phones[mine])
+        del keep, fr_l
+    else:
+        ut = ut_all
+        feats = synth.sample_feats_torch(model, ut.frame_pdf, args.seed + 2000, dev)
+    n_local = len(ut.frame_off) - 1
+    frames_global = int(ut_all.frame_off[-1])
+    del ut_all
     torch.cuda.synchronize()
 
     # One non-null HIP stream shared by torch (events, RCCL) and the khg context.  The shard is cut
@@ -203,7 +271,9 @@ def main():
         fsub = feats[int(fo[0]): int(fo[-1])]
         sets.append(UtteranceSet(ctxs[b % len(ctxs)], tm, fo - fo[0], (fsub.data_ptr(), feats), dim=D, graphs=sub))
     accs = DeviceAccs(ctxs[0], dm, tm)
-    acc_t = accs.as_torch() if dist_on else None
+    acc_t = accs.as_torch() if (dist_on and args.allreduce == "torch") else None
+    comm = make_comm(ctxs[0]) if (dist_on and args.allreduce in ("khg", "khg-f32")) else None   # None in a one-rank group
+    host_block = np.zeros(accs.size, np.float64) if args.allreduce == "host" else None
 
     T = np.diff(ut.frame_off)
     npdf = np.concatenate([np.diff(s_.pdf_lists()[0]) for s_ in sets])
@@ -236,10 +306,17 @@ def main():
             s_.acc_stats(dm, tm, accs)
         for st in streams[1:]:
             ev_b.record(st); streams[0].wait_event(ev_b)
-        if dist_on:
+        if dist_on:                                   # C1, on stream 0 right behind K3: no host synchronisation
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(streams[0])
-            dist.all_reduce(acc_t)                    # torch's current stream is stream 0
+            if acc_t is not None:
+                dist.all_reduce(acc_t)                # torch's current stream is stream 0
+            elif host_block is not None:
+                _lib.check(_lib.lib.khg_accs_download(ctxs[0].h, accs.h, _lib.ptr(host_block, C.c_double)))
+                dist.all_reduce(torch.from_numpy(host_block))
+                accs.upload(host_block)
+            else:
+                accs.allreduce(comm, wire_fp32=args.allreduce == "khg-f32")
             e1.record(streams[0])
             ar_events.append((e0, e1))
 
@@ -270,7 +347,7 @@ def main():
 
     frames_total = frames_local
     if dist_on:
-        t = torch.tensor([dt, float(frames_local)], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, float(frames_local)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -344,18 +421,20 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k1_loglikes", "achieved": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "frac_executed": k1_flops_per_launch * k1_exec_frac / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "executed_cell_fraction": k1_exec_frac,
                          "note": "achieved/frac use the dense T x P_u contract FLOPs of SURVEY 8(d); K1 evaluates only the "
                                  "(frame, pdf) cells a decoder token can read, in whole 16-frame tiles (executed_cell_fraction of them); "
-                                 "executed TFLOP/s = achieved x executed_cell_fraction",
+                                 "frac_executed = frac x executed_cell_fraction is the MFMA utilisation (what the SQ_VALU_MFMA_BUSY_CYCLES counter shows)",
                          "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
             "allreduce_ms_per_step": (sum(a_.elapsed_time(b_) for a_, b_ in ar_events) / max(len(ar_events), 1)) if ar_events else None,
             "allreduce_bytes": int(accs.size) * 8 if dist_on else None,
             "m_step": m_step,
-            "check": {"acc_total_frames": res["total_frames"] , "avg_loglike_per_frame":
+            "check": {"acc_total_frames": res["total_frames"], "frames_in_set": frames_global, "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
+            "allreduce": args.allreduce if dist_on else None,
         }
         if not args.no_cpu_baseline and world == 1:
             ncpu = min(n_local, 40000)     # enough work for a few seconds of every host core
@@ -366,6 +445,9 @@ def main():
         record = json.dumps(out)
     if dist_on:
         dist.barrier()
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
     if rank == 0:
         os.write(json_fd, (record + "\n").encode())

@@ -172,6 +172,27 @@ int khg_accs_upload(khg_ctx *ctx, khg_accs *a, const double *buf_h);
 int khg_acc_stats(khg_ctx *ctx, const khg_model *m, const khg_tm *tm, khg_utts *u, float weight,
                   khg_accs *a);
 
+/* ---- C1: cross-GPU sum of the accumulator block (one process per GPU) -------------------- */
+/* AccumAmDiagGmm::Add across jobs (csrc/mle-am-diag-gmm.cc:119-128; what Kaldi's gmm-sum-accs does on
+ * files): ONE in-place ncclAllReduce(sum, fp64) of the whole block [occ | mean_acc | var_acc | trans_acc |
+ * scalars], enqueued on the context's stream right behind khg_acc_stats -- no host synchronisation
+ * between K3, the exchange and khg_model_mle_update.  `comm` is an RCCL ncclComm_t for the context's
+ * device: the caller's own (ncclCommInitRank) or one made with khg_comm_create.  The library does not
+ * link RCCL: it binds ncclAllReduce & co. from the librccl already loaded into the process (torch's, the
+ * caller's) or loads librccl.so.1 itself.  comm == NULL: a one-rank job, nothing to exchange. */
+int khg_accs_allreduce(khg_ctx *ctx, khg_accs *a, void *comm);
+/* BASELINE.json configs[4] "fp32 stats vs CPU tolerance check": the same exchange with the block
+ * rounded to fp32 for the wire (convert -> ncclAllReduce(sum, fp32) -> widen back into the block):
+ * half the xGMI bytes, per-rank partial sums lose their low 29 bits.  comm == NULL: only the rounding. */
+int khg_accs_allreduce_f32(khg_ctx *ctx, khg_accs *a, void *comm);
+/* communicator helpers for callers without their own RCCL plumbing: rank 0 calls khg_comm_unique_id,
+ * ships the 128 bytes to the other ranks by any means (a file, MPI, torch.distributed's store), every
+ * rank then calls khg_comm_create (collective; blocks until all `nranks` ranks have called it). */
+#define KHG_COMM_ID_BYTES 128
+int khg_comm_unique_id(void *id_out /* [KHG_COMM_ID_BYTES] */);
+int khg_comm_create(khg_ctx *ctx, int32_t nranks, int32_t rank, const void *id, void **comm_out);
+int khg_comm_destroy(void *comm);
+
 /* ---- host-side M-step and helpers (no GPU needed) --------------------------------------- */
 /* DiagGmm::ComputeGconsts (csrc/diag-gmm.cc:103-147) for a ragged model; num_bad_out may be NULL */
 int khg_compute_gconsts(int32_t num_pdfs, int32_t dim, const int32_t *gauss_off,

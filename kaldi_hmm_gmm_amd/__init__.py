@@ -9,7 +9,7 @@ from .align import (AlignConfig, DecodableAmDiagGmmScaled, DecodableAmDiagGmmUnm
                     FasterDecoderOptions, LatticeArc, LatticeWeight, LinearLattice, add_transition_probs, align_batch,
                     align_utterance_wrapper)
 from .context_dep import ContextDependency, monophone_context_dependency, monophone_context_dependency_shared  # noqa: F401
-from .device import (ALIGN_DONE, ALIGN_ERROR, ALIGN_EXACT_DP, ALIGN_FALLBACK, ALIGN_RETRIED, Context, DeviceAccs,  # noqa: F401
+from .device import (ALIGN_DONE, ALIGN_ERROR, ALIGN_EXACT_DP, ALIGN_FALLBACK, ALIGN_RETRIED, Comm, Context, DeviceAccs,  # noqa: F401
                      DeviceModel, DeviceTransitions, UtteranceSet)
 from .diag_gmm import AmDiagGmm, DiagGmm  # noqa: F401
 from .fst import StdArc, StdVectorFst, modify_graph_for_careful_alignment  # noqa: F401

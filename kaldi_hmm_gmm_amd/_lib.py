@@ -108,6 +108,11 @@ SIGNATURES = {
     "khg_accs_download": (C.c_int, [vp, vp, c_f64p]),
     "khg_accs_upload": (C.c_int, [vp, vp, c_f64p]),
     "khg_acc_stats": (C.c_int, [vp, vp, vp, vp, C.c_float, vp]),
+    "khg_accs_allreduce": (C.c_int, [vp, vp, vp]),
+    "khg_accs_allreduce_f32": (C.c_int, [vp, vp, vp]),
+    "khg_comm_unique_id": (C.c_int, [vp]),
+    "khg_comm_create": (C.c_int, [vp, C.c_int32, C.c_int32, vp, C.POINTER(vp)]),
+    "khg_comm_destroy": (C.c_int, [vp]),
     "khg_compute_gconsts": (C.c_int, [C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p]),
     "khg_mle_options_default": (None, [C.POINTER(MleOptionsC)]),
     "khg_mle_am_diag_gmm_update": (

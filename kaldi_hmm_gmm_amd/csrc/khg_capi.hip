@@ -3,6 +3,7 @@
 // the launches of K1 / K2 / K3.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>   // DeviceRadixSort: the stable (pdf, frame) sort of K3's bucketing
+#include <dlfcn.h>             // RCCL is bound at run time (C1)
 
 #include <algorithm>
 #include <climits>
@@ -1016,6 +1017,7 @@ struct khg_accs {
   int64_t sumG = 0; int32_t D = 0, num_tids = 0;
   int64_t n = 0, cap = 0;
   double* buf_d = nullptr;
+  float* wire_d = nullptr; int64_t wire_cap = 0;   // fp32 wire image of the block (khg_accs_allreduce_f32 only)
   double* occ() const { return buf_d; }
   double* mean() const { return buf_d + sumG; }
   double* var() const { return buf_d + sumG + sumG * D; }
@@ -1033,7 +1035,7 @@ extern "C" int khg_accs_create(khg_ctx* ctx, const khg_model* m, const khg_tm* t
   *out = a;
   return khg_accs_zero(ctx, a);
 }
-extern "C" int khg_accs_destroy(khg_accs* a) { if (a) { DEVFREE(a->buf_d); delete a; } return KHG_OK; }
+extern "C" int khg_accs_destroy(khg_accs* a) { if (a) { DEVFREE(a->buf_d); DEVFREE(a->wire_d); delete a; } return KHG_OK; }
 extern "C" int khg_accs_zero(khg_ctx* ctx, khg_accs* a) {
   if (!ctx || !a) return khg_set_error(KHG_E_ARG, "bad arguments");
   HIPCHK(hipMemsetAsync(a->buf_d, 0, sizeof(double) * (size_t)a->n, ctx->stream));
@@ -1185,6 +1187,110 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     HIPCHK(hipGetLastError());
   }
   return KHG_OK;   // asynchronous: kernel-side errors surface at khg_ctx_sync / khg_accs_download
+}
+
+// ------------------------------------------------------------------------------------------
+// C1: the cross-GPU sum of the accumulator block, RCCL called directly.  RCCL is bound at
+// run time from whatever copy the process already holds (torch bundles one with the same SONAME; two
+// copies in one process would each want their own view of the devices), so the library has no link-time
+// dependency on it and a one-GPU user never loads it.
+namespace {
+struct KhgNcclId { char internal[KHG_COMM_ID_BYTES]; };   // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
+struct RcclApi {
+  void* h = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, KhgNcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_bind() {
+  if (g_rccl.AllReduce) return KHG_OK;
+  void* h = nullptr;
+  const char* names[] = {"librccl.so.1", "librccl.so"};
+  for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy already in the process
+  for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return khg_set_error(KHG_E_UNSUPPORTED, std::string("RCCL not available: ") + dlerror());
+  RcclApi a; a.h = h;
+  a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString)
+    return khg_set_error(KHG_E_UNSUPPORTED, "RCCL library lacks ncclAllReduce / ncclCommInitRank");
+  g_rccl = a;
+  return KHG_OK;
+}
+static int rccl_fail(const char* what, int r) {
+  return khg_set_error(KHG_E_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;   // rccl.h: ncclRedOp_t / ncclDataType_t
+__global__ __launch_bounds__(256) void c1_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) dst[i] = (float)src[i];
+}
+__global__ __launch_bounds__(256) void c1_widen(const float* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) dst[i] = (double)src[i];
+}
+}  // namespace
+
+extern "C" int khg_comm_unique_id(void* id_out) {
+  if (!id_out) return khg_set_error(KHG_E_ARG, "khg_comm_unique_id: id_out is NULL");
+  int rc = rccl_bind();
+  if (rc) return rc;
+  int r = g_rccl.GetUniqueId(id_out);
+  return r ? rccl_fail("ncclGetUniqueId", r) : KHG_OK;
+}
+extern "C" int khg_comm_create(khg_ctx* ctx, int32_t nranks, int32_t rank, const void* id, void** comm_out) {
+  if (!ctx || !id || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_comm_create: bad arguments");
+  int rc = rccl_bind();
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  KhgNcclId uid;
+  memcpy(uid.internal, id, sizeof(uid.internal));
+  void* comm = nullptr;
+  int r = g_rccl.CommInitRank(&comm, nranks, uid, rank);
+  if (r) return rccl_fail("ncclCommInitRank", r);
+  *comm_out = comm;
+  return KHG_OK;
+}
+extern "C" int khg_comm_destroy(void* comm) {
+  if (!comm) return KHG_OK;
+  int rc = rccl_bind();
+  if (rc) return rc;
+  int r = g_rccl.CommDestroy(comm);
+  return r ? rccl_fail("ncclCommDestroy", r) : KHG_OK;
+}
+extern "C" int khg_accs_allreduce(khg_ctx* ctx, khg_accs* a, void* comm) {
+  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce: bad arguments");
+  if (!comm) return KHG_OK;
+  int rc = rccl_bind();
+  if (rc) return rc;
+  KernelTimer kt(ctx, "c1_allreduce");
+  int r = g_rccl.AllReduce(a->buf_d, a->buf_d, (size_t)a->n, kNcclFloat64, kNcclSum, comm, ctx->stream);
+  return r ? rccl_fail("ncclAllReduce", r) : KHG_OK;
+}
+extern "C" int khg_accs_allreduce_f32(khg_ctx* ctx, khg_accs* a, void* comm) {
+  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_f32: bad arguments");
+  if (comm) { int rc = rccl_bind(); if (rc) return rc; }
+  if (a->wire_cap < a->n) {
+    DEVFREE(a->wire_d);
+    int rc = dev_alloc(&a->wire_d, (size_t)a->n);
+    if (rc) return rc;
+    a->wire_cap = a->n;
+  }
+  KernelTimer kt(ctx, "c1_allreduce_f32");
+  const int gb = (int)std::min<int64_t>(8192, (a->n + 255) / 256);
+  hipLaunchKernelGGL(c1_narrow, dim3(gb), dim3(256), 0, ctx->stream, a->buf_d, a->wire_d, a->n);
+  if (comm) {
+    int r = g_rccl.AllReduce(a->wire_d, a->wire_d, (size_t)a->n, kNcclFloat32, kNcclSum, comm, ctx->stream);
+    if (r) return rccl_fail("ncclAllReduce", r);
+  }
+  hipLaunchKernelGGL(c1_widen, dim3(gb), dim3(256), 0, ctx->stream, a->wire_d, a->buf_d, a->n);
+  HIPCHK(hipGetLastError());
+  return KHG_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -57,6 +57,36 @@ class Context:
             pass
 
 
+class Comm:
+    """An RCCL communicator owned by the library (khg_comm_create): rank 0 makes the 128-byte id
+    (Comm.unique_id()), the caller ships it to every rank, every rank constructs Comm(ctx, nranks, rank, id)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(lib.khg_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx: "Context", nranks: int, rank: int, uid: bytes):
+        assert len(uid) == Comm.ID_BYTES
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.h = C.c_void_p()
+        check(lib.khg_comm_create(ctx.h, self.nranks, self.rank, C.c_char_p(uid), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib.khg_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceModel:
     """AmDiagGmm uploaded as the K1 tile image + K3 row-major copy."""
 
@@ -345,6 +375,13 @@ class DeviceAccs:
         t = torch.as_tensor(w, device=f"cuda:{self.ctx.device}")
         t._khg_keepalive = self
         return t
+
+    def allreduce(self, comm: "Comm" = None, wire_fp32: bool = False):
+        """C1 (khg_accs_allreduce): in-place sum of the block over the ranks of `comm`, enqueued on the context's
+        stream behind K3.  wire_fp32: the fp32-wire tolerance experiment (khg_accs_allreduce_f32).  comm None =
+        one-rank job."""
+        fn = lib.khg_accs_allreduce_f32 if wire_fp32 else lib.khg_accs_allreduce
+        check(fn(self.ctx.h, self.h, comm.h if comm is not None else None))
 
     def split(self, buf):
         G, D, nt = self.sumG, self.dim, self.num_tids

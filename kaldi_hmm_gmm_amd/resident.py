@@ -32,7 +32,7 @@ from .transition_model import MleTransitionUpdateConfig, TransitionModel, get_pd
 class ResidentEm:
     def __init__(self, am_gmm: AmDiagGmm, transition_model: TransitionModel, fsts: Sequence[StdVectorFst],
                  feats: Sequence[np.ndarray], acoustic_scale: float = 1.0, transition_scale: float = 1.0,
-                 self_loop_scale: float = 1.0, ctx=None):
+                 self_loop_scale: float = 1.0, ctx=None, split_seed: int = 0):
         if len(fsts) != len(feats):
             raise KhgError("ResidentEm: one decoding graph per utterance")
         self.am, self.tm = am_gmm, transition_model
@@ -48,6 +48,8 @@ class ResidentEm:
         self.accs: Optional[DeviceAccs] = None
         self._upload_model()
         self.host_in_sync = True      # am_gmm holds the device model's parameters
+        self.split_seed, self._updates = int(split_seed), 0
+        self._comm, self._comm_made = None, False
 
     # -- plumbing ------------------------------------------------------------------------------
     def _set_trans_cost(self):
@@ -119,18 +121,34 @@ class ResidentEm:
         """gmm_acc_stats_ali over the shard (scripts/gmm_acc_stats_ali.py:9-58) + the cross-rank sum."""
         self.accs.zero()
         self.us.acc_stats(self.dm, self.dt, self.accs, weight)
-        try:
-            import torch.distributed as dist
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        except ImportError:
-            multi = False
-        if multi:
-            import torch
-            self.ctx.sync()                               # K3 runs on the context's own stream
-            dist.all_reduce(self.accs.as_torch(), op=dist.ReduceOp.SUM)
-            torch.cuda.current_stream().synchronize()
+        self._sum_over_ranks()
         self._tr = self.accs.download_trans()
         return {"total_log_like": self._tr["total_log_like"], "total_frames": self._tr["total_frames"]}
+
+    def _sum_over_ranks(self):
+        """C1 when torch.distributed is initialised with more than one rank: the library's own RCCL all-reduce on the
+        context's stream (backend nccl: one GPU per rank), or -- for groups that cannot carry device buffers (gloo, e.g.
+        several ranks sharing one GPU in the tests) -- the block summed on the host."""
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if dist.get_backend() == "nccl":
+            if not self._comm_made:
+                from .dist import make_comm
+                self._comm, self._comm_made = make_comm(self.ctx), True
+            self.accs.allreduce(self._comm)
+        else:
+            import torch
+            buf = np.zeros(self.accs.size, np.float64)
+            from ._lib import check, lib, ptr
+            import ctypes as C
+            check(lib.khg_accs_download(self.ctx.h, self.accs.h, ptr(buf, C.c_double)))
+            t = torch.from_numpy(buf)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self.accs.upload(buf)
 
     def update(self, tcfg: MleTransitionUpdateConfig = None, gmm_opts: MleDiagGmmOptions = None, mixup: int = 0,
                perturb_factor: float = 0.01, power: float = 0.2, min_count: float = 20.0, update_flags: str = "mvwt",
@@ -138,6 +156,13 @@ class ResidentEm:
         """gmm_est (scripts/gmm_est.py:8-96) from the resident accumulators; returns its printed statistics."""
         flags = str_to_gmm_flags(update_flags)
         gmm_opts = gmm_opts or MleDiagGmmOptions()
+        self._updates += 1
+        if randn is None:
+            # DiagGmm::Split draws from the process-global rand() in the reference (csrc/diag-gmm.cc:823); here every
+            # rank must perturb the SAME way (the model is replicated, only statistics are exchanged), so the default
+            # stream is a counter-keyed generator: identical on all ranks, reproducible across runs
+            _rng = np.random.default_rng([self.split_seed, self._updates])
+            randn = lambda d: _rng.standard_normal(d).astype(np.float32)  # noqa: E731
         tr = self._tr
         info: Dict[str, float] = {}
         if int(flags) & int(GmmUpdateFlags.kGmmTransitions):
@@ -167,6 +192,9 @@ class ResidentEm:
         return info
 
     def close(self):
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
         for o in (self.accs, self.us, self.dm, self.dt):
             if o is not None:
                 o.close()

@@ -179,21 +179,25 @@ def sample_feats(model: SynthModel, frame_pdf, rng, chunk=1 << 18):
     return out
 
 
-def sample_feats_torch(model: SynthModel, frame_pdf, seed, device, chunk=1 << 22):
-    """Same law as sample_feats, generated directly in HBM with torch (bench-sized sets)."""
+def sample_feats_torch(model: SynthModel, frame_pdf, seed, device, chunk=1 << 22, keep=None):
+    """Same law as sample_feats, generated directly in HBM with torch (bench-sized sets).
+    keep: optional boolean mask over the frames -- only those rows are stored (a rank's shard of the ONE global
+    set: every rank draws the whole stream chunk by chunk, so frame i has the same bits whoever owns it)."""
     import torch
 
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     N = frame_pdf.shape[0]
     D = model.dim
-    out = torch.empty((N, D), dtype=torch.float32, device=device)
+    n_out = N if keep is None else int(np.count_nonzero(keep))
+    out = torch.empty((n_out, D), dtype=torch.float32, device=device)
     go = torch.as_tensor(model.gauss_off.astype(np.int64), device=device)
     cw = torch.cumsum(torch.as_tensor(model.weights, device=device).double(), 0)
     base = torch.cat([torch.zeros(1, device=device, dtype=torch.float64), cw])[go[:-1]]
     means = torch.as_tensor(model.means, device=device)
     std = torch.sqrt(torch.as_tensor(model.vars, device=device))
     fp = torch.as_tensor(frame_pdf.astype(np.int64), device=device)
+    cur = 0
     for s in range(0, N, chunk):
         p = fp[s: s + chunk]
         r = torch.rand(p.shape[0], device=device, dtype=torch.float64, generator=gen)
@@ -201,5 +205,13 @@ def sample_feats_torch(model: SynthModel, frame_pdf, seed, device, chunk=1 << 22
         comp = torch.searchsorted(cw, r, right=True)
         comp = torch.minimum(torch.maximum(comp, go[p]), go[p + 1] - 1)
         z = torch.randn((p.shape[0], D), device=device, dtype=torch.float32, generator=gen)
-        out[s: s + chunk] = means[comp] + std[comp] * z
+        if keep is None:
+            out[s: s + chunk] = means[comp] + std[comp] * z
+        else:
+            k = torch.as_tensor(keep[s: s + chunk], device=device)
+            n = int(k.sum())
+            if n:
+                ck = comp[k]
+                out[cur: cur + n] = means[ck] + std[ck] * z[k]
+            cur += n
     return out

@@ -642,6 +642,68 @@ static void decoder_free(Decoder *d) {
   free(d->buckets); free((void *)d->queue); free(d->tmp_array);
 }
 
+/* ---- test hooks onto the HashList restatement above (the decoder's own code, no second copy), so that
+ * tests/test_oracle_pins.py can replay the reference's csrc/hash-list-test.cc against it.  Values are carried in
+ * the Token* slot as integers. ---- */
+void *orc_hl_create(void) {
+  Decoder *d = (Decoder *)calloc(1, sizeof(Decoder));
+  if (!d) return NULL;
+  d->bucket_list_tail = NOBUCKET;
+  d->elem_pool.item = sizeof(Elem); d->tok_pool.item = sizeof(Token);
+  return d;
+}
+void orc_hl_destroy(void *h) { if (h) { decoder_free((Decoder *)h); free(h); } }
+void orc_hl_set_size(void *h, int64_t size) { hl_set_size((Decoder *)h, (size_t)size); }
+/* hash-list-inl.h:65-83 Find */
+static Elem *hl_find(Decoder *d, int32_t key) {
+  size_t index = (size_t)key % d->hash_size;
+  Bucket *bucket = &d->buckets[index];
+  if (bucket->last_elem == NULL) return NULL;
+  Elem *head = (bucket->prev_bucket == NOBUCKET ? d->list_head : d->buckets[bucket->prev_bucket].last_elem->tail),
+       *tail = bucket->last_elem->tail;
+  for (Elem *e = head; e != tail; e = e->tail)
+    if (e->key == key) return e;
+  return NULL;
+}
+int orc_hl_find(void *h, int32_t key, int64_t *val) {
+  Elem *e = hl_find((Decoder *)h, key);
+  if (!e) return 0;
+  if (val) *val = (int64_t)(intptr_t)e->val;
+  return 1;
+}
+/* Find-then-set-or-Insert, the idiom of hash-list-test.cc:31-37 */
+void orc_hl_put(void *h, int32_t key, int64_t val) {
+  Decoder *d = (Decoder *)h;
+  Elem *e = hl_find(d, key);
+  if (e) e->val = (Token *)(intptr_t)val;
+  else hl_insert(d, key, (Token *)(intptr_t)val);
+}
+/* Insert proper: returns 1 when a new element was made, 0 when the key existed (its value is left alone, :129-143) */
+int orc_hl_insert(void *h, int32_t key, int64_t val) {
+  Elem *e = hl_insert((Decoder *)h, key, (Token *)(intptr_t)val);
+  return e && (int64_t)(intptr_t)e->val == val && 1;
+}
+/* GetList (:56-57): the elements in list order */
+int64_t orc_hl_list(void *h, int32_t *keys, int64_t *vals, int64_t cap) {
+  int64_t n = 0;
+  for (const Elem *e = ((Decoder *)h)->list_head; e != NULL; e = e->tail, ++n)
+    if (n < cap) { if (keys) keys[n] = e->key; if (vals) vals[n] = (int64_t)(intptr_t)e->val; }
+  return n;
+}
+/* hash-list-test.cc:49-59: h = Clear(); SetSize(new_size); for each old element: Insert(key + shift, val); Delete(old) */
+int64_t orc_hl_clear_reinsert(void *h, int64_t new_size, int32_t shift) {
+  Decoder *d = (Decoder *)h;
+  Elem *e = hl_clear(d), *tmp;
+  hl_set_size(d, (size_t)new_size);
+  int64_t n = 0;
+  for (; e != NULL; e = tmp, ++n) {
+    hl_insert(d, e->key + shift, e->val);
+    tmp = e->tail;
+    hl_delete(d, e);
+  }
+  return n;
+}
+
 /* decoder-wrappers.cc:16-108 with faster-decoder.cc:355-423 GetBestPath and kaldifst's
  * GetLinearSymbolSequence (restated from its Kaldi semantics) */
 static int align_core(const orc_align_config *cfg, float acoustic_scale, const orc_graph *g,

@@ -200,6 +200,17 @@ int orc_transition_mle_update(int32_t num_tstates, const int32_t *state2id,
                               float mincount, float *log_probs, float *non_self_loop_log_probs,
                               float *objf_impr, float *count);
 
+/* ---- test hooks: the decoder's HashList restatement (hash-list.h, hash-list-inl.h) driven the way the reference's
+ * csrc/hash-list-test.cc drives HashList<Int, T> ---- */
+void *orc_hl_create(void);
+void orc_hl_destroy(void *h);
+void orc_hl_set_size(void *h, int64_t size);
+int orc_hl_find(void *h, int32_t key, int64_t *val);
+void orc_hl_put(void *h, int32_t key, int64_t val);
+int orc_hl_insert(void *h, int32_t key, int64_t val);
+int64_t orc_hl_list(void *h, int32_t *keys, int64_t *vals, int64_t cap);
+int64_t orc_hl_clear_reinsert(void *h, int64_t new_size, int32_t shift);
+
 /* bench.py's cpu_baseline, variant B: `num_threads` POSIX threads run orc_align_utterance +
  * orc_acc_stats_ali per utterance (private accumulators) over utterances [first_utt, first_utt + n_utt) of a set in
  * the C-ABI's concatenated CSR layout, for at most `budget_seconds`.  Not a reference function (the reference is

@@ -70,6 +70,16 @@ def _open(path):
     l.orc_ml_objective.restype = C.c_float
     l.orc_augment_gmm_flags.restype = C.c_uint16
     l.orc_augment_gmm_flags.argtypes = [C.c_uint16]
+    l.orc_hl_create.restype = C.c_void_p
+    l.orc_hl_destroy.argtypes = [C.c_void_p]
+    l.orc_hl_set_size.argtypes = [C.c_void_p, C.c_int64]
+    l.orc_hl_find.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    l.orc_hl_put.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    l.orc_hl_insert.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    l.orc_hl_list.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int64]
+    l.orc_hl_list.restype = C.c_int64
+    l.orc_hl_clear_reinsert.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    l.orc_hl_clear_reinsert.restype = C.c_int64
     return l
 
 
@@ -355,3 +365,38 @@ def transition_mle_update(state2id, self_loop_of, stats, log_probs, nsl, floor=0
 
 def augment_gmm_flags(flags):
     return int(lib().orc_augment_gmm_flags(flags))
+
+
+class OHashList:
+    """The decoder's HashList restatement (hash-list.h, hash-list-inl.h) through the oracle's test hooks."""
+
+    def __init__(self):
+        self.h = lib().orc_hl_create()
+
+    def set_size(self, n):
+        lib().orc_hl_set_size(self.h, int(n))
+
+    def find(self, key):
+        v = C.c_int64()
+        return int(v.value) if lib().orc_hl_find(self.h, int(key), C.byref(v)) else None
+
+    def put(self, key, val):
+        lib().orc_hl_put(self.h, int(key), int(val))
+
+    def insert(self, key, val):
+        return bool(lib().orc_hl_insert(self.h, int(key), int(val)))
+
+    def items(self):
+        n = lib().orc_hl_list(self.h, None, None, 0)
+        k = np.zeros(max(n, 1), np.int32)
+        v = np.zeros(max(n, 1), np.int64)
+        lib().orc_hl_list(self.h, _p(k, C.c_int32), _p(v, C.c_int64), n)
+        return list(zip(k[:n].tolist(), v[:n].tolist()))
+
+    def clear_reinsert(self, new_size, shift=1):
+        return int(lib().orc_hl_clear_reinsert(self.h, int(new_size), int(shift)))
+
+    def close(self):
+        if self.h:
+            lib().orc_hl_destroy(self.h)
+            self.h = None

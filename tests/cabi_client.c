@@ -182,6 +182,22 @@ int main(int argc, char **argv) {
   mo.min_gaussian_occupancy = 3.0f;
   float objf = 0, cnt = 0; int32_t fe = 0, fg = 0, rm = 0;
   CHECK(khg_model_set_weights(ctx, m, w));
+  /* C1 from plain C: the library's own RCCL communicator, here over the one rank this process is; the
+   * all-reduce runs on the context's stream between K3 and K4 and must leave the one-rank block as it was */
+  {
+    char id[KHG_COMM_ID_BYTES];
+    void *comm = NULL;
+    CHECK(khg_comm_unique_id(id));
+    CHECK(khg_comm_create(ctx, 1, 0, id, &comm));
+    REQUIRE(comm != NULL);
+    CHECK(khg_accs_allreduce(ctx, acc, comm));
+    double *blk2 = (double *)malloc(sizeof(double) * (size_t)nacc);
+    CHECK(khg_accs_download(ctx, acc, blk2));
+    REQUIRE(memcmp(blk, blk2, sizeof(double) * (size_t)nacc) == 0);
+    free(blk2);
+    CHECK(khg_comm_destroy(comm));
+    CHECK(khg_accs_allreduce(ctx, acc, NULL));            /* one-rank job without a communicator: a no-op */
+  }
   CHECK(khg_model_mle_update(ctx, m, acc, &mo, 7, &objf, &cnt, &fe, &fg, &rm));
   int64_t newG = 0; int32_t new_off[P + 1];
   CHECK(khg_model_num_gauss(m, &newG, new_off));

@@ -59,3 +59,35 @@ def test_two_rank_allreduce_matches_single_process(tmp_path):
                            [acc.total_frames, acc.total_log_like]])
     np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-12)
     assert got[-2] == ut.frame_off[-1]
+
+
+def test_take_utterances_is_the_per_utterance_slice():
+    """dist.take_utterances (what bench.py and the N > 1 tests cut a rank's shard with): the sub-set's CSR graphs, frame
+    offsets and global frame indices equal the per-utterance slices of the whole set."""
+    sys.path.insert(0, ROOT)
+    from kaldi_hmm_gmm_amd import synth
+    from kaldi_hmm_gmm_amd.dist import shard_utterances, take_utterances
+
+    m = synth.make_model(30, 2, 5, seed=3)
+    ut = synth.make_utts(m, 23, seed=12, min_phones=2, max_phones=5, feats=False)
+    shards = shard_utterances(np.diff(ut.frame_off), 3)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(23))
+    loads = [int(np.diff(ut.frame_off)[s].sum()) for s in shards]
+    assert max(loads) - min(loads) <= int(np.diff(ut.frame_off).max())
+    g = ut.graphs
+    for idx in shards + [np.arange(23), np.array([22]), np.array([0, 7])]:
+        fo, gl, fr = take_utterances(ut.frame_off, g, idx)
+        assert fo[0] == 0 and gl["state_off"][0] == 0 and gl["arc_off"][0] == 0
+        for k, u in enumerate(idx):
+            T = ut.frame_off[u + 1] - ut.frame_off[u]
+            assert fo[k + 1] - fo[k] == T
+            assert np.array_equal(fr[fo[k]: fo[k + 1]], np.arange(ut.frame_off[u], ut.frame_off[u + 1]))
+            s0, s1 = g["state_off"][u], g["state_off"][u + 1]
+            l0, l1 = gl["state_off"][k], gl["state_off"][k + 1]
+            assert l1 - l0 == s1 - s0 and gl["start"][k] == g["start"][u]
+            assert np.array_equal(gl["final"][l0:l1], g["final"][s0:s1])
+            a0, a1 = g["arc_off"][s0], g["arc_off"][s1]
+            b0, b1 = gl["arc_off"][l0], gl["arc_off"][l1]
+            assert np.array_equal(gl["arc_off"][l0: l1 + 1] - b0, g["arc_off"][s0: s1 + 1] - a0)
+            for key in ("ilabel", "olabel", "weight", "nextstate"):
+                assert np.array_equal(gl[key][b0:b1], g[key][a0:a1]), key

@@ -1,0 +1,172 @@
+"""The N > 1 product path on the GPU box.  The box has ONE MI355X, so the ranks are fresh child
+processes sharing GPU 0 (tests/dist_worker.py) and their accumulator blocks are summed over gloo on the host -- RCCL
+does not form a communicator with two ranks on one device.  Everything else is what bench.py --gpus N and ResidentEm
+run: utterances dealt with shard_utterances / take_utterances, K1 -> K2 -> K3 through the C-ABI per shard, K4 on the
+summed block on every rank.  The RCCL entry points themselves (khg_comm_create, khg_accs_allreduce[_f32]) are covered
+with a one-rank communicator, and bench.py's self-launch with KHG_BENCH_SHARE_GPU=1."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawn(mode, world, tmp_path):
+    port = _port()
+    outs = [str(tmp_path / f"{mode}_r{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, "--rank", str(r), "--world", str(world),
+                               "--port", str(port), "--out", outs[r]], cwd=ROOT, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    errs = []
+    for p in procs:
+        try:
+            _, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        errs.append(e)
+    for p, e in zip(procs, errs):
+        assert p.returncode == 0, e[-3000:]
+    return [np.load(o) for o in outs]
+
+
+def test_two_ranks_sharded_em_pass_equals_single_process(ctx, tmp_path):
+    import dist_worker as dw
+    from kaldi_hmm_gmm_amd.dist import shard_utterances
+
+    got = _spawn("kernels", 2, tmp_path)
+    m, gc, cost, ut = dw.kernels_inputs()
+    shards = shard_utterances(np.diff(ut.frame_off), 2)
+    n_utt = len(ut.frame_off) - 1
+    assert sorted(np.concatenate(shards).tolist()) == list(range(n_utt))
+    PAR = ("gauss_off", "weights", "gconsts", "means_invvars", "inv_vars")
+
+    # (1) every rank ends the pass with the SAME summed block and the SAME new model, bit for bit
+    assert np.array_equal(got[0]["block"], got[1]["block"])
+    for k in PAR:
+        assert np.array_equal(got[0][k], got[1][k]), k
+    assert int(got[0]["removed"]) == int(got[1]["removed"])
+
+    # (2) this process, running the two shards one after the other and adding the two blocks (a + b: the sum of two
+    # operands does not depend on the order), reproduces the ranks' block, alignments and post-K4 model bit for bit
+    blocks = []
+    for r in range(2):
+        dm, tm, us, accs, buf, ali = dw.kernels_pass(ctx, m, gc, cost, ut, shards[r])
+        assert np.array_equal(got[r]["mine"], shards[r]) and np.array_equal(got[r]["ali"], ali)
+        assert np.array_equal(got[r]["own_block"], buf)              # K1-K3 are run-to-run and process-to-process deterministic
+        blocks.append(buf)
+        if r == 0:
+            for o in (accs, us, tm, dm):
+                o.close()
+    summed = blocks[0] + blocks[1]
+    assert np.array_equal(summed, got[0]["block"])
+    res, d = dw.kernels_mstep(dm, accs, summed)
+    for k in PAR:
+        assert np.array_equal(d[k], got[0][k]), k
+    for o in (accs, us, tm, dm):
+        o.close()
+
+    # (3) against ONE process over the whole set: alignments identical per utterance, integer statistics exact, the
+    # fp64 sums equal up to the association of the additions (1e-12), the new parameters to float rounding
+    dm, tm, us, accs, whole, ali_all = dw.kernels_pass(ctx, m, gc, cost, ut, np.arange(n_utt))
+    for r in range(2):
+        fo = ut.frame_off
+        want = np.concatenate([ali_all[fo[u]: fo[u + 1]] for u in shards[r]])
+        assert np.array_equal(got[r]["ali"], want)
+    sp = accs.split(whole)
+    gp = accs.split(got[0]["block"].copy())
+    assert np.array_equal(sp["trans_acc"], gp["trans_acc"]) and sp["total_frames"] == gp["total_frames"] == ut.frame_off[-1]
+    np.testing.assert_allclose(gp["occ"], sp["occ"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gp["mean_acc"], sp["mean_acc"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(gp["var_acc"], sp["var_acc"], rtol=1e-12, atol=1e-9)
+    assert gp["total_log_like"] == pytest.approx(sp["total_log_like"], rel=1e-12)
+    res1, d1 = dw.kernels_mstep(dm, accs, whole)
+    assert np.array_equal(d1["gauss_off"], got[0]["gauss_off"]) and res1["removed"] == int(got[0]["removed"])
+    np.testing.assert_allclose(got[0]["weights"], d1["weights"], rtol=3e-7)
+    np.testing.assert_allclose(got[0]["inv_vars"], d1["inv_vars"], rtol=2e-6)
+    np.testing.assert_allclose(got[0]["means_invvars"], d1["means_invvars"], rtol=2e-6, atol=1e-6)
+    for o in (accs, us, tm, dm):
+        o.close()
+
+
+def test_resident_em_two_ranks_hold_identical_models(ctx, tmp_path):
+    """every rank must split (mix up) the same way.  Two ranks run ResidentEm on their shards for four
+    passes with mixing up and the default perturbation stream: bit-identical models on both ranks, the same number of
+    Gaussians and (to rounding) the same likelihoods as one process over the whole set."""
+    import dist_worker as dw
+    import kaldi_hmm_gmm_amd as khg
+
+    got = _spawn("resident", 2, tmp_path)
+    for k in ("gauss_off", "weights", "gconsts", "means_invvars", "inv_vars", "log_probs", "log"):
+        assert np.array_equal(got[0][k], got[1][k]), k
+    ex, tm, am, graphs, feats, ali = dw.resident_inputs()
+    em = khg.ResidentEm(am, tm, graphs, feats, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1, ctx=ctx)
+    em.set_alignments(ali)
+    log = np.asarray(dw.resident_run(em, ex), np.float64)
+    go = em.sync_host().flat()[0]
+    em.close()
+    assert np.array_equal(go, got[0]["gauss_off"]) and go[-1] > 11            # mixed up, and identically so
+    assert np.array_equal(log[:, 0], got[0]["log"][:, 0]) and log[0, 0] == sum(f.shape[0] for f in feats)   # frames: all of them, every pass
+    np.testing.assert_allclose(got[0]["log"][:, 1], log[:, 1], rtol=1e-5)
+
+
+def test_rccl_entry_points_with_a_one_rank_communicator(ctx):
+    """khg_comm_unique_id / khg_comm_create / khg_accs_allreduce / khg_accs_allreduce_f32 on the real RCCL (bound at run
+    time from the copy torch loaded): the sum over one rank is the identity; the fp32 wire rounds the block to float."""
+    import dist_worker as dw
+    from kaldi_hmm_gmm_amd import Comm
+
+    m, gc, cost, ut = dw.kernels_inputs()
+    dm, tm, us, accs, buf, _ = dw.kernels_pass(ctx, m, gc, cost, ut, np.arange(8))
+    comm = Comm(ctx, 1, 0, Comm.unique_id())
+    accs.allreduce(comm)
+    ctx.sync()
+    assert np.array_equal(accs.download_range(0, accs.size), buf)
+    accs.allreduce(comm, wire_fp32=True)
+    ctx.sync()
+    assert np.array_equal(accs.download_range(0, accs.size), buf.astype(np.float32).astype(np.float64))
+    accs.upload(buf)
+    accs.allreduce(None)                                   # one-rank job: no communicator, nothing to do
+    accs.allreduce(None, wire_fp32=True)                   # only the rounding
+    ctx.sync()
+    assert np.array_equal(accs.download_range(0, accs.size), buf.astype(np.float32).astype(np.float64))
+    comm.close()
+    for o in (accs, us, tm, dm):
+        o.close()
+
+
+def test_bench_launches_its_own_ranks_and_shards_the_one_set():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun around it): the parent starts the ranks, relays ONE
+    JSON line; the two ranks own the frames of the N = 1 set (same seeds) and the summed accumulators count all of
+    them.  KHG_BENCH_SHARE_GPU=1: both ranks on GPU 0, block summed on the host."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--utts", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r1 = subprocess.run(base, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=900, env=dict(env, KHG_BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines = r2.stdout.strip().splitlines()
+    assert len(lines) == 1, r2.stdout[:2000]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and d2["allreduce"] == "host"
+    f = d1["config"]["frames_per_step"]
+    assert d2["config"]["frames_per_step"] == f == d1["check"]["frames_in_set"] == d2["check"]["frames_in_set"]
+    assert d1["check"]["acc_total_frames"] == f and d2["check"]["acc_total_frames"] == f        # rank 0 holds the sum over both shards
+    assert d2["check"]["avg_loglike_per_frame"] == pytest.approx(d1["check"]["avg_loglike_per_frame"], rel=1e-9)
+    assert d2["allreduce_ms_per_step"] is not None and d2["allreduce_bytes"] > 0 and d2["value"] > 0
+    assert d2["roofline"]["frac_executed"] <= d2["roofline"]["frac"] < 1.0

@@ -135,3 +135,78 @@ def test_threaded_em_pass_driver_counts_every_utterance():
     assert utts == 3 and frames == ut.frame_off[7] - ut.frame_off[4]
     frames, utts, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, num_threads=2, budget_seconds=0.0, acoustic_scale=0.1)
     assert utts == 0 and frames == 0
+
+
+# ---- the literal stored answers the reference holds on this path (csrc/eigen-test.cc, csrc/hash-list-test.cc) ----
+LSE_V5 = [0.1, 0.3, 0.2, 0.15, 0.25]                                               # csrc/eigen-test.cc:461-464 -> 1.8119
+LSE_V10 = [-0.028933119028806686, -0.8265501260757446, 0.31104734539985657, 0.25977903604507446, 0.18070533871650696,
+           0.02222185768187046, -1.4124598503112793, -0.5896500945091248, -0.17299121618270874, -0.6516317129135132]   # :466-473 -> 2.1343
+SOFTMAX_V = [0.46589261293411255, 0.5329158902168274, 0.45468050241470337, 0.509181022644043, 0.4529399275779724]   # :642-644
+SOFTMAX_EXPECTED = [0.1964813768863678, 0.21010152995586395, 0.19429071247577667, 0.205173522233963, 0.19395282864570618]   # :646-648
+
+
+def test_logsumexp_stored_vectors():
+    # csrc/eigen-test.cc:460-475: EXPECT_NEAR(f, 1.8119, 1e-4); EXPECT_NEAR(f, 2.1343, 1e-4)
+    assert abs(orc.logsumexp(LSE_V5) - 1.8119) < 1e-4
+    assert abs(orc.logsumexp(LSE_V10) - 2.1343) < 1e-4
+
+
+def test_softmax_stored_vector():
+    # csrc/eigen-test.cc:641-655: EXPECT_NEAR(expected[i], actual[i], 1e-4)
+    post, lse = orc.softmax(SOFTMAX_V)
+    assert np.abs(post - np.asarray(SOFTMAX_EXPECTED, np.float32)).max() < 1e-4
+    assert lse == pytest.approx(math.log(sum(math.exp(v) for v in SOFTMAX_V)), abs=1e-5)
+    # the same numbers through the GMM entry points the hot path uses: a 1-dim pdf with zero means / inv_vars has
+    # component log-likelihoods == gconsts, so LogLikelihood is LogSumExp(v) and ComponentPosteriors is Softmax(v)
+    for v, want in ((LSE_V5, 1.8119), (LSE_V10, 2.1343)):
+        g = np.asarray(v, np.float32)
+        z = np.zeros((len(v), 1), np.float32)
+        m = orc.OModel(np.array([0, len(v)], np.int32), g, z, z)
+        ll = orc.loglikes_matrix(m, np.array([[0.7]], np.float32), np.array([0], np.int32))
+        assert abs(float(ll[0, 0]) - want) < 1e-4
+    g = np.asarray(SOFTMAX_V, np.float32)
+    z = np.zeros((5, 1), np.float32)
+    post2, _ = orc.component_posteriors(orc.OModel(np.array([0, 5], np.int32), g, z, z), 0, np.array([0.3], np.float32))
+    assert np.abs(np.asarray(post2) - np.asarray(SOFTMAX_EXPECTED, np.float32)).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed,key_mod,val_mod", [(0, 200, 50), (1, 200, 50), (2, 127, 50), (3, 256, 50), (4, 200, 7), (5, 200, 50)])
+def test_hash_list_behaviour(seed, key_mod, val_mod):
+    """csrc/hash-list-test.cc:19-87 replayed against the oracle's HashList restatement (the decoder's own code): fifty
+    find-or-insert operations against a std::map baseline, then 100 rounds of Clear -> SetSize(100 + rand % 100) ->
+    re-Insert every element under key + 1 -> Delete, checking after every round that the list holds exactly the
+    baseline's pairs and that Find agrees with the baseline on ten random keys.  (key_mod 127 / 256 stand for the
+    reference's int16 / char instantiations, whose keys wrap; here keys stay below 2^31.)"""
+    rng = np.random.default_rng(1000 + seed)
+    h = orc.OHashList()
+    h.set_size(200)
+    m1 = {}
+    for _ in range(50):
+        key, val = int(rng.integers(0, key_mod)), int(rng.integers(0, val_mod))
+        m1[key] = val
+        h.put(key, val)
+    assert dict(h.items()) == m1 and len(h.items()) == len(m1)
+    for _ in range(100):
+        m1 = {k + 1: v for k, v in m1.items()}
+        n = h.clear_reinsert(100 + int(rng.integers(0, 100)), shift=1)
+        assert n == len(m1)
+        items = h.items()
+        assert len(items) == len(m1) and dict(items) == m1
+        for _ in range(10):
+            key = int(rng.integers(0, key_mod + 100))
+            assert h.find(key) == m1.get(key)
+    h.close()
+
+
+def test_hash_list_insert_keeps_the_first_value_and_list_is_bucket_ordered():
+    """hash-list-inl.h:129-174: Insert on an existing key returns the existing element (value untouched) -- what
+    FasterDecoder::ProcessEmitting's `e_found->val != new_tok` test relies on (faster-decoder.cc:213-227); a new
+    bucket goes to the END of the list, a key hashing into an occupied bucket goes right after that bucket's last
+    element: the iteration order the order-faithful decoder kernels must reproduce."""
+    h = orc.OHashList()
+    h.set_size(10)
+    assert h.insert(3, 30) and h.insert(7, 70) and h.insert(13, 130) and h.insert(5, 50)
+    assert not h.insert(7, 71) and h.find(7) == 70
+    assert h.items() == [(3, 30), (13, 130), (7, 70), (5, 50)]          # 13 % 10 == 3: behind key 3, ahead of 7
+    assert h.find(23) is None and h.find(4) is None
+    h.close()
