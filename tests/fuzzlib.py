@@ -1,0 +1,259 @@
+"""Randomised parity sweeps and the larger end-to-end check, as functions: tests/test_gpu_fuzz.py runs seeded, time-boxed
+slices of them under `pytest -m gpu`; tests/manual/*.py are the open-ended command-line forms (hours-long sweeps).
+
+fuzz_graphs   GENERAL decoding graphs: left-to-right graphs with branches and long skips (in-degree up to 6), epsilon-input
+              arcs carrying word labels, unreachable finals, empty graphs, utterances too short to reach the end; random
+              beams (pruning, retries, max_active).  K1's own scores feed both sides: status / alignment / words must
+              equal the oracle's FasterDecoder exactly.
+fuzz_parity   random model / utterance shapes and beams: K1 against the fp64 bound, K2 bit-exact on identical scores,
+              K3 and the device M-step (K4) against the oracle.
+validate_large  K1 -> K2 -> K3 end to end on bench-like utterances (long, ~75 pdfs each, 64 Gaussians) against the
+              oracle pipeline: a mismatch REPORT (SURVEY.md 7 hard part (ii)), not only a pass/fail."""
+import time
+
+import numpy as np
+
+from graphs import concat, random_graph
+from helpers import build, exact_loglikes, oracle_graph, utt_feats
+from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, DeviceTransitions, MleDiagGmmOptions, UtteranceSet, synth
+from oracle import oracle as orc
+
+EMPTY = {"start": -1, "arc_off": np.zeros(1, np.int64), "ilabel": np.zeros(0, np.int32), "olabel": np.zeros(0, np.int32),
+         "weight": np.zeros(0, np.float32), "nextstate": np.zeros(0, np.int32), "final": np.zeros(0, np.float32)}
+
+
+def fuzz_graphs(ctx, budget=120.0, seed=1):
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); n = nutt = nfall = nerr = nret = 0
+    while time.time() - t0 < budget:
+        P = int(rng.choice([3, 6, 12, 30])); G = int(rng.choice([1, 3, 8])); D = int(rng.choice([2, 8, 13]))
+        seed = int(rng.integers(1 << 30))
+        m = synth.make_model(P, G, D, seed=seed)
+        gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+        U = int(rng.integers(1, 14))
+        p_eps = float(rng.choice([0.0, 0.0, 0.2, 0.6])); p_br = float(rng.choice([0.0, 0.3, 0.8])); p_long = float(rng.choice([0.0, 0.5, 0.9]))
+        graphs = []
+        for _ in range(U):
+            r = rng.random()
+            if r < 0.04:
+                graphs.append(EMPTY)
+            else:
+                graphs.append(random_graph(rng, m.num_tids, n_main=int(rng.integers(1, 40)), p_branch=p_br, p_eps=p_eps, with_final=r > 0.1, p_long=p_long))
+        if all(g is EMPTY for g in graphs):       # a set without any state is a features-only set by the C-ABI's contract
+            graphs[0] = random_graph(rng, m.num_tids, n_main=3)
+        T = [int(rng.integers(max(1, len(g["final"]) - 2), len(g["final"]) + 40)) for g in graphs]
+        if rng.random() < 0.2:
+            T[int(rng.integers(U))] = 0
+        frame_off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+        scale = float(rng.choice([0.1, 0.3, 1.0]))
+        feats = (rng.standard_normal((max(int(frame_off[-1]), 1), D)) * float(rng.choice([0.5, 3.0]))).astype(np.float32)[: int(frame_off[-1])]
+        dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+        tm = DeviceTransitions(ctx, m.id2pdf)
+        tm.set_trans_cost(np.zeros(m.num_tids + 1, np.float32))
+        us = UtteranceSet(ctx, tm, frame_off, feats if feats.shape[0] else np.zeros((0, D), np.float32), graphs=concat(graphs))
+        us.loglikes(dm, reachable_only=bool(rng.integers(2)))
+        us.loglikes(dm)                      # full scores for the oracle (unreadable cells are unspecified otherwise)
+        lls = us.download_loglikes()
+        poff, pdfs = us.pdf_lists()
+        beam, retry = [(200.0, 0.0), (16.0, 0.0), (6.0, 40.0), (2.0, 8.0), (0.5, 1.0)][int(rng.integers(5))]
+        kw = {}
+        if rng.random() < 0.25:
+            kw = {"max_active": int(rng.choice([2, 5, 30])), "min_active": int(rng.choice([0, 1]))}
+        tag = f"P{P} G{G} D{D} U{U} eps{p_eps} br{p_br} long{p_long} beam{beam}/{retry} scale{scale} {kw} seed{seed}"
+        res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=scale, **kw)
+        for u, g in enumerate(graphs):
+            og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+            ll = lls[u] if lls[u].size else np.zeros((1, max(T[u], 1)), np.float32)
+            want = orc.align_utterance_ll(og, m.id2pdf, T[u], pdfs[poff[u]: poff[u + 1]], ll, acoustic_scale=scale, beam=beam, retry_beam=retry, **kw)
+            st = int(res["status"][u])
+            assert (st & 1) == (want["status"] & 1), (tag, u, st, want["status"])
+            if g["start"] >= 0:
+                assert (st & 2) == (want["status"] & 2), (tag, u, st, want["status"])
+            a = res["ali"][frame_off[u]: frame_off[u + 1]]
+            nfall += (st & 8) != 0; nret += (st & 2) != 0
+            if want["status"] & 1:
+                nerr += 1
+                assert (a == 0).all(), (tag, u)
+            else:
+                assert (a == want["ali"]).all(), (tag, u)
+                w = res["words"][res["words_off"][u]: res["words_off"][u + 1]]
+                assert (w == want["words"]).all(), (tag, u, "words")
+                assert abs(res["like"][u] - want["like"]) <= 1e-5 * abs(want["like"]) + 1e-4, (tag, u, "like")
+        n += 1; nutt += U
+        us.close(); tm.close(); dm.close()
+    return {"batches": n, "utterances": nutt, "oracle_failed": int(nerr), "retried": int(nret), "fallback": int(nfall), "seconds": time.time() - t0}
+
+
+def fuzz_parity(ctx, budget=120.0, seed=1):
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); n = 0; nutt = 0; nfall = 0; nerr = 0
+    while time.time() - t0 < budget:
+        P = int(rng.choice([3, 6, 12, 30, 60, 150]))
+        G = int(rng.choice([1, 2, 3, 8, 16, 17, 32, 48, 64, 65, 100, 128]))
+        D = int(rng.choice([1, 5, 13, 23, 39, 40, 41, 64, 80]))
+        ragged = bool(rng.integers(2))
+        lo = int(rng.choice([1, 2, 5, 20])); hi = lo + int(rng.choice([0, 2, 10, 30]))
+        U = int(rng.choice([1, 3, 9, 20]))
+        beam, retry = [(200.0, 0.0), (20.0, 0.0), (8.0, 40.0), (3.0, 10.0), (1.0, 2.0)][int(rng.integers(5))]
+        seed = int(rng.integers(1 << 30))
+        tag = f"P{P} G{G} D{D} ragged{int(ragged)} phones{lo}-{hi} U{U} beam{beam}/{retry} seed{seed}"
+        m, gc, om, ut, cost = build(P, G, D, n_utt=U, seed=seed, ragged=ragged, min_phones=lo, max_phones=hi)
+        if int(np.diff(ut.graphs["state_off"]).max()) > 1400:
+            continue
+        dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+        tm = DeviceTransitions(ctx, m.id2pdf); tm.set_trans_cost(cost)
+        us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
+        # K1 against the fp64 bound (the tolerance of tests/test_gpu_parity.py)
+        us.loglikes(dm)
+        got_ll = us.download_loglikes()
+        poff, pdfs = us.pdf_lists()
+        mats = []
+        for u in range(U):
+            pl = pdfs[poff[u]: poff[u + 1]]
+            exact, bound = exact_loglikes(m, gc, utt_feats(ut, u), pl)
+            assert (np.abs(got_ll[u] - exact) <= 1e-5 + 1e-6 * bound).all(), (tag, u, "K1")
+            mats.append(orc.loglikes_matrix(om, utt_feats(ut, u), pl))
+        # K2 on IDENTICAL scores (the oracle's): alignment, status, words bit-exact whatever the beam does
+        us.upload_loglikes(mats)
+        res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1)
+        oa = orc.OAccs(int(m.gauss_off[-1]), D, m.num_tids)
+        ali_ok = np.zeros(ut.frame_off[-1], np.int32)
+        for u in range(U):
+            f = utt_feats(ut, u)
+            T = int(ut.frame_off[u + 1] - ut.frame_off[u])
+            want = orc.align_utterance_ll(oracle_graph(ut, u, cost), m.id2pdf, T, pdfs[poff[u]: poff[u + 1]], mats[u], acoustic_scale=0.1,
+                                          beam=beam, retry_beam=retry)
+            st = int(res["status"][u])
+            assert (st & 3) == (want["status"] & 3), (tag, u, st, want["status"])
+            nfall += (st & 8) != 0
+            sl = slice(ut.frame_off[u], ut.frame_off[u + 1])
+            if want["status"] & 1:
+                nerr += 1
+                assert (res["ali"][sl] == 0).all(), (tag, u)
+                continue
+            assert (res["ali"][sl] == want["ali"]).all(), (tag, u)
+            assert abs(res["like"][u] - want["like"]) <= 1e-6 * abs(want["like"]) + 1e-4, (tag, u)
+            ali_ok[sl] = want["ali"]
+            orc.acc_stats_ali(om, m.id2pdf, f, want["ali"], oa)
+        accs = DeviceAccs(ctx, dm, tm)
+        us.acc_stats(dm, tm, accs)
+        got = accs.download()
+        assert (got["trans_acc"] == oa.trans_acc).all(), tag
+        np.testing.assert_allclose(got["occ"], oa.occ, rtol=2e-4, atol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-4, atol=2e-5 * max(1e-30, np.abs(oa.mean_acc).max()), err_msg=tag)
+        np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-4, atol=2e-5 * max(1e-30, np.abs(oa.var_acc).max()), err_msg=tag)
+        occ_min = float(rng.choice([0.5, 3.0, 10.0])); fl = int(rng.choice([7, 5, 4, 2, 3, 1]))
+        r = dm.mle_update(accs, MleDiagGmmOptions(min_gaussian_occupancy=occ_min), fl)
+        d = dm.download()
+        for p in range(P):
+            a, b = int(m.gauss_off[p]), int(m.gauss_off[p + 1])
+            w = orc.mle_diag_gmm_update(m.weights[a:b], m.means_invvars[a:b], m.inv_vars[a:b], got["occ"][a:b], got["mean_acc"][a:b],
+                                        got["var_acc"][a:b], acc_flags=0xF, flags=fl, min_gaussian_occupancy=occ_min)
+            a2, b2 = int(d["gauss_off"][p]), int(d["gauss_off"][p + 1])
+            assert b2 - a2 == len(w["weights"]), (tag, p, "removed")
+            for k in ("weights", "inv_vars", "means_invvars"):
+                assert np.array_equal(d[k][a2:b2], w[k]), (tag, p, k)
+            # gconst = log w - D/2 log 2pi + sum_d (1/2 log iv - 1/2 miv^2 / iv), float accumulator: the logf difference shows up at
+            # the ulp of the largest partial sum (with tiny D the terms can cancel to a much smaller result)
+            ivf, mivf = w["inv_vars"].astype(np.float64), w["means_invvars"].astype(np.float64)
+            big = np.abs(np.log(w["weights"].astype(np.float64))) + 0.5 * 1.8378770664093453 * D + (0.5 * np.abs(np.log(ivf)) + 0.5 * mivf * mivf / ivf).sum(1)
+            dgc = np.abs(d["gconsts"][a2:b2] - w["gconsts"])
+            if not (dgc <= 4 * np.spacing(big.astype(np.float32))).all():
+                i = int((dgc / np.spacing(big.astype(np.float32))).argmax())
+                raise AssertionError((tag, p, "gconsts", i, float(d["gconsts"][a2 + i]), float(w["gconsts"][i]), float(big[i]), float(w["weights"][i]),
+                                      w["inv_vars"][i].tolist(), w["means_invvars"][i].tolist(), occ_min, fl))
+        n += 1; nutt += U
+        us.close(); accs.close(); tm.close(); dm.close()
+    return {"configurations": n, "utterances": nutt, "oracle_failed": int(nerr), "fallback": int(nfall), "seconds": time.time() - t0}
+
+
+def _path_cost(graph_u, cost_tid, ali, ll_rows, col_of_pdf, id2pdf, acoustic_scale):
+    """Cost of the path an alignment spells on a graph whose out-arcs of a state carry distinct transition-ids (every
+    compiled training graph): sum of arc weights (+ AddTransitionProbs) minus acoustic_scale * log-likes, in double.
+    -> (cost, final state reached) ; None when the tid sequence is not a path."""
+    s = int(graph_u["start"])
+    ao, il, w, ns, fin = graph_u["arc_off"], graph_u["ilabel"], graph_u["weight"], graph_u["nextstate"], graph_u["final"]
+    c = 0.0
+    for t, tid in enumerate(ali):
+        hit = [a for a in range(int(ao[s]), int(ao[s + 1])) if il[a] == tid]
+        if len(hit) != 1:
+            return None
+        a = hit[0]
+        c += float(w[a]) + float(cost_tid[tid]) - acoustic_scale * float(ll_rows[col_of_pdf[int(id2pdf[tid])], t])
+        s = int(ns[a])
+    if not np.isfinite(fin[s]):
+        return None
+    return c + float(fin[s])
+
+
+def validate_large(ctx, n_utt=300, shape=(600, 64, 40), beams=((200.0, 0.0), (6.0, 40.0)), seed=91, near_tie=1e-3, flat_noise=None):
+    """-> report dict.  Per beam setting: status mismatches, alignment mismatches and, for every mismatching utterance,
+    the cost difference of the two paths re-scored on the ORACLE's log-likes (a mismatch is only tolerable as a near-tie:
+    |delta cost| <= near_tie, i.e. the two implementations' fp32 score rounding decided between two equally good paths)."""
+    P, G, D = shape
+    m, gc, om, ut, cost = build(P, G, D, n_utt=n_utt, seed=seed, min_phones=10, max_phones=40)
+    if flat_noise is not None:
+        # score with a MISMATCHED model, like the flat start of a recipe: one broad Gaussian per pdf at the global mean,
+        # means perturbed by flat_noise sigma -- scores of different pdfs are close, the beam prunes for real, retries and
+        # the order-faithful decoders are exercised, near-ties exist
+        rng = np.random.default_rng(seed + 7)
+        mean, var = ut.feats.mean(0), ut.feats.var(0)
+        iv = np.tile((1.0 / var).astype(np.float32), (P, 1))
+        miv = ((mean[None, :] + flat_noise * np.sqrt(var)[None, :] * rng.standard_normal((P, D))).astype(np.float32) * iv).astype(np.float32)
+        m.gauss_off, m.weights, m.inv_vars, m.means_invvars = np.arange(P + 1, dtype=np.int32), np.ones(P, np.float32), iv, miv
+        gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+        om = orc.OModel(m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    tm.set_trans_cost(cost)
+    us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
+    poff, pdfs = us.pdf_lists()
+    rep = {"shape": {"pdfs": P, "gauss": G if flat_noise is None else 1, "dim": D}, "scoring_model": "generating model" if flat_noise is None
+           else f"flat-start-like (1 broad Gaussian per pdf, means perturbed {flat_noise} sigma)", "utterances": n_utt, "frames": int(ut.frame_off[-1]), "near_tie_bound": near_tie,
+           "runs": []}
+    g = ut.graphs
+    for beam, retry in beams:
+        us.loglikes(dm, reachable_only=True)
+        res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1)
+        accs = DeviceAccs(ctx, dm, tm)
+        us.acc_stats(dm, tm, accs)
+        got = accs.download()
+        accs.close()
+        oa = orc.OAccs(int(m.gauss_off[-1]), m.dim, m.num_tids)
+        t0 = time.time()
+        status_bad, ali_bad, like_err, deltas = 0, 0, 0.0, []
+        for u in range(n_utt):
+            f = utt_feats(ut, u)
+            want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, f, acoustic_scale=0.1, beam=beam, retry_beam=retry)
+            a = res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]]
+            if (int(res["status"][u]) & 3) != (want["status"] & 3):
+                status_bad += 1
+                continue
+            if want["status"] & 1:
+                continue
+            like_err = max(like_err, abs(float(res["like"][u]) - want["like"]) / max(1.0, abs(want["like"])))
+            if not np.array_equal(a, want["ali"]):
+                ali_bad += 1
+                pl = pdfs[poff[u]: poff[u + 1]]
+                ll = orc.loglikes_matrix(om, f, pl)
+                col = {int(p): j for j, p in enumerate(pl)}
+                s0, s1 = int(g["state_off"][u]), int(g["state_off"][u + 1])
+                a0 = int(g["arc_off"][s0])
+                gu = {"start": g["start"][u], "arc_off": g["arc_off"][s0: s1 + 1] - a0, "ilabel": g["ilabel"][a0: int(g["arc_off"][s1])],
+                      "weight": g["weight"][a0: int(g["arc_off"][s1])], "nextstate": g["nextstate"][a0: int(g["arc_off"][s1])], "final": g["final"][s0:s1]}
+                c_gpu = _path_cost(gu, cost, a, ll, col, m.id2pdf, 0.1)
+                c_orc = _path_cost(gu, cost, want["ali"], ll, col, m.id2pdf, 0.1)
+                deltas.append(None if c_gpu is None or c_orc is None else abs(c_gpu - c_orc))
+            orc.acc_stats_ali(om, m.id2pdf, f, want["ali"], oa)
+        rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))   # noqa: E731
+        rep["runs"].append({
+            "beam": beam, "retry_beam": retry, "status_mismatches": status_bad, "alignment_mismatches": ali_bad,
+            "alignment_mismatch_rate": ali_bad / n_utt, "mismatch_path_cost_deltas": deltas,
+            "max_rel_like_err": like_err, "trans_acc_equal": bool(np.array_equal(got["trans_acc"], oa.trans_acc)) if ali_bad == 0 else None,
+            "occ_max_err_rel_to_max": rel(got["occ"], oa.occ), "mean_acc_max_err_rel_to_max": rel(got["mean_acc"], oa.mean_acc),
+            "var_acc_max_err_rel_to_max": rel(got["var_acc"], oa.var_acc),
+            "retried": int(((res["status"] & 2) != 0).sum()), "fallback_decoder": int(((res["status"] & 8) != 0).sum()),
+            "oracle_seconds": time.time() - t0})
+    for o in (us, tm, dm):
+        o.close()
+    return rep

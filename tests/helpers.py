@@ -47,3 +47,29 @@ def exact_loglikes(m, gc, feats, pdfs):
         bb = np.abs(g)[None, :] + np.abs(x) @ np.abs(miv).T + 0.5 * (x * x) @ iv.T
         bound[j] = bb.max(1)
     return out, bound
+
+
+def token_path_cost(graphs, u, ali, ll_u, pdf_list, cost, id2pdf, acoustic_scale):
+    """Walk utterance u's graph along the transition-id sequence `ali` (out-arcs of a state carry distinct ids in the
+    compiled training graphs): -> (is an accepting path, its cost in the token arithmetic of faster-decoder.h:119-137:
+    double(prev) + float(arc weight + AddTransitionProbs) + float(-(scale * ll)), left to right, + final weight)."""
+    g = graphs
+    s0 = int(g["state_off"][u])
+    ao = g["arc_off"]
+    col = {int(p): j for j, p in enumerate(pdf_list)}
+    st = int(g["start"][u])
+    scale = np.float32(acoustic_scale)
+    terms = np.empty(2 * len(ali), np.float64)
+    for t, tid in enumerate(ali):
+        a0, a1 = int(ao[s0 + st]), int(ao[s0 + st + 1])
+        k = np.nonzero(g["ilabel"][a0:a1] == tid)[0]
+        if k.size != 1:
+            return False, np.inf
+        a = a0 + int(k[0])
+        terms[2 * t] = np.float32(g["weight"][a] + cost[tid])                              # AddTransitionProbs: float add
+        terms[2 * t + 1] = np.float32(-1) * (scale * ll_u[col[int(id2pdf[tid])], t])        # decodable-am-diag-gmm.h:96
+        st = int(g["nextstate"][a])
+    fin = g["final"][s0 + st]
+    if not np.isfinite(fin):
+        return False, np.inf
+    return True, float(np.add.accumulate(terms)[-1] + np.float64(fin))

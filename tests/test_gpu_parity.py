@@ -430,3 +430,27 @@ def test_reachable_only_loglikes_skip_only_unreadable_cells(ctx, k1_form):
     assert np.array_equal(res["ali"], res_full["ali"]) and np.array_equal(res["status"], res_full["status"])
     np.testing.assert_array_equal(res["like"], res_full["like"])
     print("skipped fraction", skipped / total)
+
+
+def test_reference_stored_logsumexp_softmax_vectors_through_k1_and_k3(ctx):
+    """The only literal stored answers the reference holds for LogSumExp / Softmax (csrc/eigen-test.cc:460-475, :641-655),
+    through the product's kernels: a 1-dim pdf with zero means_invvars / inv_vars has component log-likelihoods ==
+    gconsts, so K1's fused log-sum-exp must give 1.8119 / 2.1343 and K3's posteriors the stored Softmax vector, at the
+    reference's own tolerance (1e-4) -- and agree with the oracle to float rounding."""
+    from kaldi_hmm_gmm_amd import _gpu
+    from test_oracle_pins import LSE_V10, LSE_V5, SOFTMAX_EXPECTED, SOFTMAX_V
+
+    _gpu.set_default_context(ctx)
+    x = np.array([[0.7], [-1.3], [0.0]], np.float32)
+    for v, want in ((LSE_V5, 1.8119), (LSE_V10, 2.1343)):
+        g = np.asarray(v, np.float32)
+        z = np.zeros((len(v), 1), np.float32)
+        ll = _gpu.loglikes(np.array([0, len(v)], np.int32), g, z, z, x, [0])
+        assert ll.shape == (1, 3) and (np.abs(ll - want) < 1e-4).all()
+        assert (np.abs(ll - orc.logsumexp(v)) <= 2e-6).all()
+    g = np.asarray(SOFTMAX_V, np.float32)
+    z = np.zeros((5, 1), np.float32)
+    st = _gpu.acc_stats(np.array([0, 5], np.int32), g, z, z, x[:1], [0])
+    assert np.abs(st["occ"] - np.asarray(SOFTMAX_EXPECTED)).max() < 1e-4
+    post, lse = orc.softmax(SOFTMAX_V)
+    assert np.abs(st["occ"] - post).max() <= 2e-7 and abs(st["total_log_like"] - lse) <= 2e-6
