@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense" (the bare v_mfma_f32_32x32x16_bf16 loop of
+#                                 tools/mfma_bf16_chain.hip holds 1.78-1.85 PF on this chip: the clock drops to ~1.8 GHz under it)
 
 
 def parse():
@@ -38,6 +40,10 @@ def parse():
     ap.add_argument("--batches", type=int, default=1, help="utterance batches per rank (more batches bound the score/back-pointer buffers and let a batch's serial fallback decoder overlap the next batch's K1)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
+    ap.add_argument("--k1", choices=["auto", "bf16x3", "pdf", "utt"], default="auto",
+                    help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = bf16x3 (bf16 matrix cores at fp32 accuracy); pdf / utt = "
+                         "the fp32-MFMA forms")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the two extra steps that time the fp32-MFMA K1 beside a bf16x3 run")
     ap.add_argument("--seed", type=int, default=20230418)
     ap.add_argument("--allreduce", choices=["khg", "torch", "khg-f32", "host"], default="khg",
                     help="C1: khg = khg_accs_allreduce (RCCL called by the library on the kernels' stream); torch = "
@@ -252,6 +258,10 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
     torch.cuda.set_stream(streams[0])
     ctxs = [Context(local, stream=st.cuda_stream) for st in streams]
+    env_k1 = os.environ.get("KHG_K1")
+    k1_form = {"fp32": "pdf"}.get(env_k1, env_k1) if env_k1 in ("bf16x3", "pdf", "utt", "fp32") else ("bf16x3" if args.k1 == "auto" else args.k1)
+    for c in ctxs:
+        c.set_k1_form(k1_form)
     dm = DeviceModel(ctxs[0], model.gauss_off, gc, model.means_invvars, model.inv_vars)
     tm = DeviceTransitions(ctxs[0], model.id2pdf)
     tm.set_trans_cost(cost)
@@ -286,7 +296,10 @@ def main():
             poff_, _ = s_.pdf_lists()
             first = s_.pdf_first_frames().astype(np.int64)
             Tu = np.repeat(np.diff(s_.frame_off), np.diff(poff_))
-            skipped_cells += float(np.minimum(16 * (first // 16), Tu).sum())
+            if k1_form == "bf16x3":                 # whole 32-frame tiles (first needed 16-frame tile, clamped to 127, halved)
+                skipped_cells += float(np.minimum(32 * (np.minimum(first // 16, 127) // 2), Tu).sum())
+            else:
+                skipped_cells += float(np.minimum(16 * (first // 16), Tu).sum())
     k1_exec_frac = 1.0 - skipped_cells / max(float((T * npdf).sum()), 1.0)
     kernel_ms = {}
     ev_a = torch.cuda.Event()
@@ -357,6 +370,42 @@ def main():
     k1_avg_ms = k1_total_ms / n_local_launches
     k1_flops_per_launch = k1_flops / nb
 
+    # the fp32-MFMA K1 beside a bf16x3 run: the same step, K1 switched to the pdf-major fp32 kernel (1 warm-up + 2 timed steps)
+    fp32_line = None
+    if k1_form == "bf16x3" and not args.no_fp32_line:
+        for c in ctxs:
+            c.set_k1_form("pdf")
+        step()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.sync()
+            c.set_timing(True)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        dt32 = time.perf_counter() - t0
+        k32 = {}
+        for c in ctxs:
+            for name, ms in c.timings():
+                k32[name] = k32.get(name, 0.0) + ms
+            c.set_timing(False)
+            c.set_k1_form(k1_form)
+        if dist_on:
+            t32 = torch.tensor([dt32], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t32, op=dist.ReduceOp.MAX)
+            dt32 = float(t32[0])
+        k1_32 = k32.get("k1_loglikes", 0.0) / (2 * nb)
+        fp32_line = {"k1": "fp32 MFMA (v_mfma_f32_16x16x4_f32), pdf-major", "steps": 2, "ms_per_step": dt32 / 2 * 1e3,
+                     "value": frames_total * 2 / dt32, "k1_kernel_ms": k1_32,
+                     "roofline_frac": k1_flops_per_launch / (k1_32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if k1_32 else None}
+        ar_events[:] = ar_events[: args.steps]
+
     if rank == 0:
         tm0 = time.perf_counter()
         res = accs.download()
@@ -401,6 +450,36 @@ def main():
                   "note": "not part of value (SURVEY 8d: M-step reported separately); host = threaded C++ update between an "
                           "accumulator download and a parameter upload; device = K4 on the accumulators where K3 left them"}
         traffic, traffic_src = pmc_traffic(frames_local / nb)
+        cells = k1_flops_per_launch / (4.0 * D * G + 5.0 * G)          # (frame, pdf) cells per launch, dense contract
+        t_k1 = k1_avg_ms * 1e-3
+        if k1_form == "bf16x3":
+            # every fp32 multiply-add of the contraction is six bf16 multiply-adds (khg_k1_bf16x3.hip.inc): the bf16 FLOPs of the
+            # SURVEY 8(d) contract are cells x (6 x 4DG + 5G), priced against the dense bf16 MFMA peak
+            bflops = cells * (24.0 * D * G + 5.0 * G)
+            roofline = {"bound": "mfma", "kernel": "k1_loglikes (k1b_loglikes: v_mfma_f32_32x32x16_bf16, bf16x3)", "achieved": bflops / t_k1 / 1e12,
+                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bflops / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        "frac_executed": bflops * k1_exec_frac / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        "fp32_equivalent": {"achieved": k1_flops_per_launch / t_k1 / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": k1_flops_per_launch / t_k1 / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                            "note": "the SURVEY 8(d) fp32 contract FLOPs (4DG + 5G per cell) over the same time, against the fp32-MFMA "
+                                                    "peak the fp32 kernels are bound by: > 1 means past that roofline"},
+                        "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                        "executed_cell_fraction": k1_exec_frac,
+                        "note": "achieved/frac: bf16 FLOPs of the dense T x P_u contract (6 bf16 partial products per fp32 product) / kernel time "
+                                "/ the 2.5 PFLOP/s dense bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame tiles "
+                                "(executed_cell_fraction); frac_executed = frac x that fraction.  Under a bare bf16 MFMA loop this chip holds "
+                                "1.8 GHz = 1.8 PFLOP/s (tools/mfma_bf16_chain.hip), 0.72 of the spec peak",
+                        "kernel_ms": k1_avg_ms, "flops_per_launch": bflops, "launches_per_step": nb}
+        else:
+            ach = k1_flops_per_launch / t_k1 / 1e12
+            roofline = {"bound": "mfma", "kernel": "k1_loglikes (fp32 MFMA, %s)" % k1_form, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "frac_executed": ach * k1_exec_frac / PEAK_F32_MFMA_TFLOPS,
+                        "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                        "executed_cell_fraction": k1_exec_frac,
+                        "note": "achieved/frac use the dense T x P_u contract FLOPs of SURVEY 8(d); K1 evaluates only the (frame, pdf) cells a "
+                                "decoder token can read, in whole 16-frame tiles (executed_cell_fraction of them); frac_executed = frac x "
+                                "executed_cell_fraction is the MFMA utilisation (what the SQ_VALU_MFMA_BUSY_CYCLES counter shows)",
+                        "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb}
         out = {
             "metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss",
             "value": frames_total * args.steps / dt,
@@ -412,22 +491,19 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if k1_form != "bf16x3" else "f32 via bf16x3",
+            "dtype_note": None if k1_form != "bf16x3" else
+            "log-likelihood contraction: fp32 operands split EXACTLY into three bf16 pieces, the six partial products of weight >= 2^-16 on "
+            "the bf16 matrix cores, fp32 accumulate -- measured error vs fp64 BELOW the fp32 fmaf chain's (max 4.4e-7 B vs 6.0e-7 B, "
+            "gpurun_out/probe_bf16x3.txt), every fp64-bound tolerance test unchanged; everything else fp32 / fp64 as the reference; the "
+            "fp32-MFMA K1 is timed beside it in fp32_mfma_line (--k1 pdf runs it as the whole bench)",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} pdfs x {G} Gauss, dim {D}, {args.utts} utterances "
                                    f"({frames_total} frames) sharded over {world} GPU(s), beam {args.beam:g}, "
                                    f"acoustic_scale 0.1, mean pdfs/utt {npdf.mean():.1f}",
                        "frames_per_step": frames_total, "utterances": args.utts},
-            "roofline": {"bound": "mfma", "kernel": "k1_loglikes", "achieved": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": k1_flops_per_launch / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "frac_executed": k1_flops_per_launch * k1_exec_frac / (k1_avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "executed_cell_fraction": k1_exec_frac,
-                         "note": "achieved/frac use the dense T x P_u contract FLOPs of SURVEY 8(d); K1 evaluates only the "
-                                 "(frame, pdf) cells a decoder token can read, in whole 16-frame tiles (executed_cell_fraction of them); "
-                                 "frac_executed = frac x executed_cell_fraction is the MFMA utilisation (what the SQ_VALU_MFMA_BUSY_CYCLES counter shows)",
-                         "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb},
+            "roofline": roofline,
+            "fp32_mfma_line": fp32_line,
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
             "allreduce_ms_per_step": (sum(a_.elapsed_time(b_) for a_, b_ in ar_events) / max(len(ar_events), 1)) if ar_events else None,
             "allreduce_bytes": int(accs.size) * 8 if dist_on else None,

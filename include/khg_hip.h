@@ -50,6 +50,21 @@ int khg_ctx_set_timing(khg_ctx *ctx, int on);
 int khg_ctx_get_timings(khg_ctx *ctx, char *names, int64_t names_cap, float *ms, int32_t cap,
                         int32_t *n_out);
 
+/* Which arithmetic K1 (khg_loglikes*) runs in.  All forms evaluate decodable-am-diag-gmm.cc:55-61 to fp32 accuracy
+ * (|error| <= 1e-5 + 1e-6 B against an fp64 evaluation, B = |gconst| + sum |M x| + sum |V x^2| / 2; the reference's own
+ * Eigen gemv fixes no summation order either):
+ *   KHG_K1_BF16X3    (what AUTO selects) both operands split exactly into three bf16 pieces, the six partial products of
+ *                    weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: measured error BELOW the fp32
+ *                    chain's (gpurun_out/probe_bf16x3.txt), 16x the matrix rate for 6x the steps;
+ *   KHG_K1_FP32_PDF / KHG_K1_FP32_UTT   fp32 MFMA (v_mfma_f32_16x16x4_f32), pdf-major / utterance-major tiling: bit for bit the
+ *                    per-Gaussian chain s = gconst; s = fmaf(M[d], x[d], s) ...; s = fmaf(-V[d]/2, x[d]^2, s) ... in k order.
+ * The environment variable KHG_K1 = bf16x3 | pdf | utt overrides the setting (A/B runs). */
+#define KHG_K1_AUTO 0
+#define KHG_K1_BF16X3 1
+#define KHG_K1_FP32_PDF 2
+#define KHG_K1_FP32_UTT 3
+int khg_ctx_set_k1_form(khg_ctx *ctx, int form);
+
 /* ---- acoustic model ------------------------------------------------------------------- */
 /* AmDiagGmm (csrc/am-diag-gmm.h:96) as flat ragged arrays: pdf p owns Gaussians
  * [gauss_off[p], gauss_off[p+1]) with DiagGmm's exponential-form parameters

@@ -75,6 +75,7 @@ SIGNATURES = {
     "khg_ctx_destroy": (C.c_int, [vp]),
     "khg_ctx_sync": (C.c_int, [vp]),
     "khg_ctx_set_timing": (C.c_int, [vp, C.c_int]),
+    "khg_ctx_set_k1_form": (C.c_int, [vp, C.c_int]),
     "khg_ctx_get_timings": (C.c_int, [vp, C.c_char_p, C.c_int64, c_f32p, C.c_int32, c_i32p]),
     "khg_model_create": (C.c_int, [vp, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, c_f32p, C.POINTER(vp)]),
     "khg_model_destroy": (C.c_int, [vp]),

@@ -21,6 +21,7 @@
 
 #include "khg_k1_loglikes.hip.inc"
 #include "khg_k1_pdfmajor.hip.inc"
+#include "khg_k1_bf16x3.hip.inc"
 #include "khg_k2_viterbi.hip.inc"
 #include "khg_k3_accstats.hip.inc"
 #include "khg_k4_mstep.hip.inc"
@@ -49,6 +50,7 @@ struct khg_ctx {
   int32_t* err_flag_d = nullptr;
   bool timing = false;
   std::vector<khg_timing> timings;
+  int k1_form = KHG_K1_AUTO;      // khg_ctx_set_k1_form; the KHG_K1 environment variable overrides it
 };
 // scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled)
 struct KernelTimer {
@@ -136,6 +138,11 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
   *n_out = n;
   return KHG_OK;
 }
+extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) {
+  if (!c || form < KHG_K1_AUTO || form > KHG_K1_FP32_UTT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_k1_form: bad arguments");
+  c->k1_form = form;
+  return KHG_OK;
+}
 static int check_err_flag(khg_ctx* c, const char* where);
 extern "C" int khg_ctx_sync(khg_ctx* c) {
   if (!c) return khg_set_error(KHG_E_ARG, "ctx is NULL");
@@ -203,6 +210,8 @@ struct khg_model {
   float* weights_d = nullptr;   // only the device M-step needs them (khg_model_set_weights)
   bool has_weights = false;
   int32_t wimg_tiles = 0;       // tiles wimg_d was allocated for
+  char* wimgb_d = nullptr;      // bf16x3 K1 image (khg_k1_bf16x3.hip.inc), k1b_tile_bytes(KS) per 32-Gaussian tile
+  int32_t wimgb_tiles = 0, KS = 0;
 };
 
 // (Re)build everything derived from gauss_off + the row-major parameters in HBM: the tile offsets, the K1
@@ -227,6 +236,13 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     if (rc) return rc;
     m->wimg_tiles = nt;
   }
+  m->KS = m->KQ == 10 ? 5 : 10;
+  if (!m->wimgb_d || m->wimgb_tiles < nt) {
+    DEVFREE(m->wimgb_d);
+    int rc = dev_alloc(&m->wimgb_d, (size_t)nt * k1b_tile_bytes(m->KS));
+    if (rc) return rc;
+    m->wimgb_tiles = nt;
+  }
   std::vector<int32_t> tile_pdf((size_t)nt);   // tile -> pdf map for the pack kernel
   for (int p = 0; p < P; ++p)
     for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
@@ -236,6 +252,8 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     KernelTimer kt(ctx, "k0_pack_tiles");
     if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
     else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+    if (m->KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d);
+    else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d);
   }
   if (!rc) {
     hipError_t e = hipGetLastError();
@@ -276,7 +294,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 }
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
-  DEVFREE(m->wimg_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
@@ -351,6 +369,9 @@ struct khg_utts {
   K1pEntry* p_ents_d = nullptr; K1pSlice* p_slices_d = nullptr; int32_t p_nslices = 0; int p_reach = -1; int32_t p_P = -1;
   int32_t p_grp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // slices per block count (index 1..8); the plan also depends on the model's gauss_off
   std::vector<int32_t> p_goff;
+  // K1, bf16x3 form: B fragments of the features (once), workgroup chunks
+  k1b_u32x4* xb3_d = nullptr; int64_t* utt_x32_off_d = nullptr; int32_t xb3_ks = 0;
+  K1bChunk* bchunks_d = nullptr; int32_t n_bchunks = 0, bchunk_nt = 0;
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
@@ -554,6 +575,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
+  DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
@@ -706,6 +728,95 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
   return KHG_OK;
 }
 
+// per-utterance W-tile walk for this model's tile layout (it only changes when the number of Gaussians of some pdf
+// crosses a multiple of 32): for every pdf on the utterance's list its 32-Gaussian tiles in order.  Entry = tile id
+// (bits 0-21) | first needed 16-frame tile of the pdf, clamped to 127 (bits 22-28; 0 unless reachable_only) |
+// last-tile-of-pdf flag (bit 31).  Shared by the utterance-major fp32 kernel and the bf16x3 kernel.
+static int ensure_walk(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
+  if (u->tiles_pto == m->pdf_tile_off && u->tiles_reach == (int)reachable_only) return KHG_OK;
+  if (m->ntiles >= (1 << 22)) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: more than 4M W tiles");
+  DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
+  std::vector<int64_t> toff((size_t)u->n_utt + 1, 0);
+  std::vector<int32_t> tiles;
+  for (int i = 0; i < u->n_utt; ++i) {
+    for (int64_t k = u->pdf_off[i]; k < u->pdf_off[i + 1]; ++k) {
+      const int p = u->pdfs[(size_t)k];
+      int ef = 0;
+      if (reachable_only) ef = (int)std::min<int64_t>(127, (int64_t)u->pdf_first[(size_t)k] / 16);
+      for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t)
+        tiles.push_back(t | (ef << 22) | (t + 1 == m->pdf_tile_off[p + 1] ? (int32_t)0x80000000 : 0));
+    }
+    toff[(size_t)i + 1] = (int64_t)tiles.size();
+  }
+  int rc = dev_upload(ctx, &u->tile_off_d, toff);
+  if (!rc) rc = dev_upload(ctx, &u->tiles_d, tiles);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  u->tiles_pto = m->pdf_tile_off;
+  u->tiles_reach = (int)reachable_only;
+  return KHG_OK;
+}
+
+// K1 on the bf16 matrix cores (khg_k1_bf16x3.hip.inc): B fragments of the features (once per set), chunks, walk.
+static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
+  int rc = KHG_OK;
+  const int KS = m->KS, NTMAX = KS == 5 ? 2 : 1;
+  if (!u->xb3_d || u->xb3_ks != KS) {
+    DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d);
+    std::vector<int64_t> xoff((size_t)u->n_utt + 1, 0);
+    for (int i = 0; i < u->n_utt; ++i) xoff[(size_t)i + 1] = xoff[(size_t)i] + (u->frame_off[i + 1] - u->frame_off[i] + 31) / 32;
+    const int64_t nx = xoff[(size_t)u->n_utt];
+    std::vector<int32_t> xutt((size_t)nx);
+    std::vector<K1bChunk> ch;
+    const int per = 8 * NTMAX;
+    for (int i = 0; i < u->n_utt; ++i) {
+      const int n32 = (int)(xoff[(size_t)i + 1] - xoff[(size_t)i]);
+      for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
+      if (u->pdf_off[i + 1] == u->pdf_off[i]) continue;
+      // chunks of equal size (a 17-tile utterance becomes 9 + 8 tiles, not 16 + 1)
+      const int nch = (n32 + per - 1) / per;
+      for (int c = 0; c < nch; ++c) {
+        const int t0 = (int)((int64_t)n32 * c / nch), t1 = (int)((int64_t)n32 * (c + 1) / nch);
+        if (t1 > t0) ch.push_back(K1bChunk{i, t0, t1 - t0, 0});
+      }
+    }
+    int32_t* xutt_d = nullptr;
+    rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
+    if (!rc) rc = dev_upload(ctx, &xutt_d, xutt);
+    if (!rc) rc = dev_upload(ctx, &u->bchunks_d, ch);
+    if (!rc) rc = dev_alloc(&u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
+    if (!rc && nx > 0) {
+      const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
+      if (KS == 5) hipLaunchKernelGGL(k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, xutt_d, nx, u->D, u->xb3_d);
+      else hipLaunchKernelGGL(k1b_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, xutt_d, nx, u->D, u->xb3_d);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    }
+    DEVFREE(xutt_d);
+    if (rc) return rc;
+    u->xb3_ks = KS; u->n_bchunks = (int32_t)ch.size(); u->bchunk_nt = NTMAX;
+  }
+  rc = ensure_walk(ctx, m, u, reachable_only);
+  if (rc) return rc;
+  K1bArgs a;
+  a.xb = u->xb3_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->bchunks_d;
+  a.wimg = m->wimgb_d; a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
+  a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
+  a.dbg = getenv("KHG_K1B_DBG") ? atoi(getenv("KHG_K1B_DBG")) : 0;
+  if (u->n_bchunks > 0) {
+    const size_t lds = (size_t)k1b_ring(KS) * k1b_tile_bytes(KS);
+    const void* fn = KS == 5 ? (const void*)k1b_loglikes<5, 2> : (const void*)k1b_loglikes<10, 1>;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer kt(ctx, "k1_loglikes");
+    if (KS == 5) hipLaunchKernelGGL((k1b_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  u->ll_valid = true;
+  return KHG_OK;
+}
+
 static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
   if (u->pdf_first.size() != u->pdfs.size()) reachable_only = false;
@@ -722,12 +833,20 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     if (rc) return rc;
   }
   {
-    // ---- pdf-major K1 (khg_k1_pdfmajor.hip.inc): pdfs of <= 128 Gaussians ----
+    // which K1: bf16x3 (default: the bf16 matrix cores at fp32 accuracy), or one of the fp32-MFMA forms -- pdf-major (pdfs of
+    // <= 128 Gaussians) / utterance-major -- whose per-Gaussian fmaf chain is pinned bit for bit by the tests
+    int form = ctx->k1_form;
+    if (const char* env = getenv("KHG_K1")) {
+      if (strcmp(env, "bf16x3") == 0) form = KHG_K1_BF16X3;
+      else if (strcmp(env, "pdf") == 0 || strcmp(env, "fp32") == 0) form = KHG_K1_FP32_PDF;
+      else if (strcmp(env, "utt") == 0) form = KHG_K1_FP32_UTT;
+    }
+    if (form == KHG_K1_AUTO) form = KHG_K1_BF16X3;
+    if (u->N == 0 || u->pdfs.empty()) { u->ll_valid = true; return KHG_OK; }
+    if (form == KHG_K1_BF16X3) return loglikes_bf16x3(ctx, m, u, reachable_only);
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
-    const char* env = getenv("KHG_K1");
-    const bool want = env ? (strcmp(env, "pdf") == 0) : true;
-    if (want && maxG <= 128 && u->N > 0 && !u->pdfs.empty()) return loglikes_pdf_major(ctx, m, u, reachable_only);
+    if (form == KHG_K1_FP32_PDF && maxG <= 128) return loglikes_pdf_major(ctx, m, u, reachable_only);
   }
   if (!u->chunks_d || u->chunk_kq != m->KQ * 16 + k1_nf(m->KQ)) {
     DEVFREE(u->chunks_d);
@@ -752,32 +871,8 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
   }
-  if (u->tiles_pto != m->pdf_tile_off || u->tiles_reach != (int)reachable_only) {
-    // per-utterance W-tile walk for this model's tile layout (it only changes when the number of
-    // Gaussians of some pdf crosses a multiple of 32): for every pdf on the utterance's list its
-    // tiles in order.  Entry = tile id (bits 0-21) | first needed 16-frame tile of the pdf, clamped
-    // to 127 (bits 22-28; 0 unless reachable_only) | last-tile-of-pdf flag (bit 31).
-    if (m->ntiles >= (1 << 22)) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: more than 4M W tiles");
-    DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
-    std::vector<int64_t> toff((size_t)u->n_utt + 1, 0);
-    std::vector<int32_t> tiles;
-    for (int i = 0; i < u->n_utt; ++i) {
-      for (int64_t k = u->pdf_off[i]; k < u->pdf_off[i + 1]; ++k) {
-        const int p = u->pdfs[(size_t)k];
-        int ef = 0;
-        if (reachable_only) ef = (int)std::min<int64_t>(127, (int64_t)u->pdf_first[(size_t)k] / 16);
-        for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t)
-          tiles.push_back(t | (ef << 22) | (t + 1 == m->pdf_tile_off[p + 1] ? (int32_t)0x80000000 : 0));
-      }
-      toff[(size_t)i + 1] = (int64_t)tiles.size();
-    }
-    rc = dev_upload(ctx, &u->tile_off_d, toff);
-    if (!rc) rc = dev_upload(ctx, &u->tiles_d, tiles);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    u->tiles_pto = m->pdf_tile_off;
-    u->tiles_reach = (int)reachable_only;
-  }
+  rc = ensure_walk(ctx, m, u, reachable_only);
+  if (rc) return rc;
   K1Args a;
   a.feats = u->feats_d; a.frame_off = u->frame_off_d; a.chunks = u->chunks_d; a.wimg = m->wimg_d;
   a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;

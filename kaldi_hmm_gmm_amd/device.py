@@ -32,6 +32,13 @@ class Context:
     def sync(self):
         check(lib.khg_ctx_sync(self.h))
 
+    K1_FORMS = {"auto": 0, "bf16x3": 1, "fp32": 2, "pdf": 2, "utt": 3}
+
+    def set_k1_form(self, form: str):
+        """Arithmetic / tiling of the log-likelihood kernel (khg_ctx_set_k1_form): "auto" (= "bf16x3"), "bf16x3", "pdf"
+        (fp32 MFMA, pdf-major), "utt" (fp32 MFMA, utterance-major)."""
+        check(lib.khg_ctx_set_k1_form(self.h, Context.K1_FORMS[form]))
+
     def set_timing(self, on: bool):
         check(lib.khg_ctx_set_timing(self.h, int(on)))
 

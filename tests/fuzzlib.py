@@ -188,8 +188,10 @@ def _path_cost(graph_u, cost_tid, ali, ll_rows, col_of_pdf, id2pdf, acoustic_sca
 
 def validate_large(ctx, n_utt=300, shape=(600, 64, 40), beams=((200.0, 0.0), (6.0, 40.0)), seed=91, near_tie=1e-3, flat_noise=None):
     """-> report dict.  Per beam setting: status mismatches, alignment mismatches and, for every mismatching utterance,
-    the cost difference of the two paths re-scored on the ORACLE's log-likes (a mismatch is only tolerable as a near-tie:
-    |delta cost| <= near_tie, i.e. the two implementations' fp32 score rounding decided between two equally good paths)."""
+    the cost difference of the two paths re-scored on the ORACLE's log-likes, and whether the oracle's decoder, fed the GPU's
+    own log-likelihoods, reproduces the GPU's alignment bit for bit.  A mismatch is tolerable only as a consequence of fp32
+    score rounding: either a near-tie between two paths (|delta cost| <= near_tie) or -- with a beam that really prunes -- a
+    last-bit difference deciding a pruning comparison, in which case the decoders must agree exactly on identical scores."""
     P, G, D = shape
     m, gc, om, ut, cost = build(P, G, D, n_utt=n_utt, seed=seed, min_phones=10, max_phones=40)
     if flat_noise is not None:
@@ -221,7 +223,8 @@ def validate_large(ctx, n_utt=300, shape=(600, 64, 40), beams=((200.0, 0.0), (6.
         accs.close()
         oa = orc.OAccs(int(m.gauss_off[-1]), m.dim, m.num_tids)
         t0 = time.time()
-        status_bad, ali_bad, like_err, deltas = 0, 0, 0.0, []
+        status_bad, ali_bad, like_err, deltas, explained = 0, 0, 0.0, [], []
+        gpu_ll = None
         for u in range(n_utt):
             f = utt_feats(ut, u)
             want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, f, acoustic_scale=0.1, beam=beam, retry_beam=retry)
@@ -231,8 +234,9 @@ def validate_large(ctx, n_utt=300, shape=(600, 64, 40), beams=((200.0, 0.0), (6.
                 continue
             if want["status"] & 1:
                 continue
-            like_err = max(like_err, abs(float(res["like"][u]) - want["like"]) / max(1.0, abs(want["like"])))
-            if not np.array_equal(a, want["ali"]):
+            if np.array_equal(a, want["ali"]):
+                like_err = max(like_err, abs(float(res["like"][u]) - want["like"]) / max(1.0, abs(want["like"])))
+            else:
                 ali_bad += 1
                 pl = pdfs[poff[u]: poff[u + 1]]
                 ll = orc.loglikes_matrix(om, f, pl)
@@ -244,11 +248,22 @@ def validate_large(ctx, n_utt=300, shape=(600, 64, 40), beams=((200.0, 0.0), (6.
                 c_gpu = _path_cost(gu, cost, a, ll, col, m.id2pdf, 0.1)
                 c_orc = _path_cost(gu, cost, want["ali"], ll, col, m.id2pdf, 0.1)
                 deltas.append(None if c_gpu is None or c_orc is None else abs(c_gpu - c_orc))
+                # is the difference all in the SCORES?  The oracle's decoder on the GPU's own log-likelihoods must return the
+                # GPU's alignment bit for bit (then the two decoders are identical and a last-bit difference of a score
+                # decided a pruning comparison or a tie)
+                if gpu_ll is None:
+                    us.loglikes(dm)
+                    gpu_ll = us.download_loglikes()
+                    us.loglikes(dm, reachable_only=True)
+                w2 = orc.align_utterance_ll(oracle_graph(ut, u, cost), m.id2pdf, f.shape[0], pl, gpu_ll[u], acoustic_scale=0.1, beam=beam,
+                                            retry_beam=retry)
+                explained.append(bool((w2["status"] & 3) == (int(res["status"][u]) & 3) and np.array_equal(w2["ali"], a)))
             orc.acc_stats_ali(om, m.id2pdf, f, want["ali"], oa)
         rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))   # noqa: E731
         rep["runs"].append({
             "beam": beam, "retry_beam": retry, "status_mismatches": status_bad, "alignment_mismatches": ali_bad,
             "alignment_mismatch_rate": ali_bad / n_utt, "mismatch_path_cost_deltas": deltas,
+            "mismatch_reproduced_by_oracle_decoder_on_gpu_scores": explained,
             "max_rel_like_err": like_err, "trans_acc_equal": bool(np.array_equal(got["trans_acc"], oa.trans_acc)) if ali_bad == 0 else None,
             "occ_max_err_rel_to_max": rel(got["occ"], oa.occ), "mean_acc_max_err_rel_to_max": rel(got["mean_acc"], oa.mean_acc),
             "var_acc_max_err_rel_to_max": rel(got["var_acc"], oa.var_acc),

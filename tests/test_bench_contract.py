@@ -28,12 +28,24 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     d = _run({}, "--cpu-baseline-seconds", "3")
     assert KEYS <= set(d), KEYS - set(d)
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["higher_is_better"] is True
-    assert d["value"] > 1e6 and d["ms_per_step"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["value"] > 1e6 and d["ms_per_step"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32 via bf16x3" and d["dtype_note"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] < 1.0 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
+    assert rf["peak"] == 2500.0 and rf["fp32_equivalent"]["peak"] == 157.3 and 0.0 < rf["frac_executed"] <= rf["frac"]
+    # the fp32-MFMA K1 timed beside it, same steps otherwise
+    f32 = d["fp32_mfma_line"]
+    assert f32["value"] > 1e6 and f32["k1_kernel_ms"] > 0 and 0.0 < f32["roofline_frac"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "frames/s" and cb["sample"]
     assert d["m_step"]["device"]["params_bit_equal_to_host"] is True
+
+
+@pytest.mark.gpu
+def test_bench_with_the_fp32_mfma_k1():
+    d = _run({}, "--no-cpu-baseline", "--k1", "pdf")
+    assert d["dtype"] == "f32" and d["fp32_mfma_line"] is None
+    rf = d["roofline"]
+    assert rf["peak"] == 157.3 and 0.0 < rf["frac_executed"] <= rf["frac"] < 1.0
 
 
 @pytest.mark.gpu

@@ -34,7 +34,7 @@ def _device(ctx, m, gc, ut, cost):
 
 @pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, False), (60, 32, 40, True), (30, 64, 40, False),
                                           (24, 20, 13, True), (12, 128, 80, False)])
-def test_loglikes_vs_oracle(ctx, P, G, D, ragged):
+def test_loglikes_vs_oracle(ctx, P, G, D, ragged, k1_form):
     m, gc, om, ut, cost = build(P, G, D, n_utt=6, seed=P + G, ragged=ragged, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
     us.loglikes(dm)
@@ -54,7 +54,7 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
-@pytest.mark.parametrize("k1", ["pdf", "utt"])
+@pytest.mark.parametrize("k1", ["bf16x3", "pdf", "utt"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (24, 20, 13), (12, 128, 80)])
 def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
     """Same bound with the means pulled together (many components contribute to every log-sum-exp instead of one)."""
@@ -88,9 +88,17 @@ def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
     assert np.mean(spread) > 0.5
 
 
-@pytest.fixture(params=["pdf", "utt"])
+@pytest.fixture(params=["bf16x3", "pdf", "utt"])
 def k1_form(request, monkeypatch):
-    """Both K1 forms: pdf-major (default for <= 64 Gaussians per pdf) and utterance-major (KHG_K1=utt)."""
+    """Every K1 form: bf16x3 (the default: bf16 matrix cores at fp32 accuracy) and the two fp32-MFMA tilings, pdf-major
+    and utterance-major."""
+    monkeypatch.setenv("KHG_K1", request.param)
+    return request.param
+
+
+@pytest.fixture(params=["pdf", "utt"])
+def k1_fp32_form(request, monkeypatch):
+    """The fp32-MFMA forms, whose contraction is pinned bit for bit to the k-ordered fmaf chain."""
     monkeypatch.setenv("KHG_K1", request.param)
     return request.param
 
@@ -124,7 +132,7 @@ def test_loglikes_long_utterances(ctx, G, D, k1_form):
     us.close()
 
 
-def test_loglikes_fma_order_bitwise_gemm(ctx, k1_form):
+def test_loglikes_fma_order_bitwise_gemm(ctx, k1_fp32_form):
     """The MFMA contraction is bit-for-bit the k-ordered fmaf chain the oracle restates; only
     exp/log differ, so with G == 1 (log-sum-exp of one term == that term) results are bit-equal."""
     m, gc, om, ut, cost = build(30, 1, 40, n_utt=3, seed=5)

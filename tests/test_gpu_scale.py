@@ -30,13 +30,25 @@ def test_em_pass_properties_at_bench_shape(ctx, monkeypatch):
     tm.set_trans_cost(cost)
     us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
 
-    # ---- K1: two kernels, one answer ----
+    # ---- K1: two fp32-MFMA tilings, one answer; the bf16x3 form (the default) within the fp32 bound of them ----
+    monkeypatch.setenv("KHG_K1", "pdf")
     us.loglikes(dm)
     ll = us.download_loglikes()
     monkeypatch.setenv("KHG_K1", "utt")
     us.loglikes(dm)
     ll_utt = us.download_loglikes()
     monkeypatch.delenv("KHG_K1")
+    us.loglikes(dm)
+    ll_b = us.download_loglikes()
+    from helpers import exact_loglikes
+    poff0, pdfs0 = us.pdf_lists()
+    for u in (0, U // 3, U - 1):
+        pl = pdfs0[poff0[u]: poff0[u + 1]][:8]
+        exact, bound = exact_loglikes(m, gc, ut.feats[ut.frame_off[u]: ut.frame_off[u + 1]], pl)
+        assert (np.abs(ll_b[u][:8] - exact) <= 1e-5 + 1e-6 * bound).all() and (np.abs(ll[u][:8] - exact) <= 1e-5 + 1e-6 * bound).all()
+    # everywhere: the two arithmetics differ by fp32 rounding of sums of ~1e3 (B), far below anything an alignment can see
+    assert max(float(np.abs(x - y).max()) for x, y in zip(ll, ll_b)) < 2e-3
+    assert all(np.isfinite(x).all() for x in ll_b)
     # same per-Gaussian fmaf chains; the log-sum-exp folds the Gaussians in a different order: <= 2 float ulps
     worst = max(float(np.max(np.abs(x - y) / np.spacing(np.abs(x)))) for x, y in zip(ll, ll_utt))
     same = sum(int((x == y).sum()) for x, y in zip(ll, ll_utt)) / sum(x.size for x in ll)
@@ -64,7 +76,7 @@ def test_em_pass_properties_at_bench_shape(ctx, monkeypatch):
                 return False, np.inf
             a = a0 + int(k[0])
             w = np.float32(g["weight"][a] + cost[tid])                       # AddTransitionProbs: float add
-            ac = np.float32(-1) * (scale * ll[u][col[int(m.id2pdf[tid])], t])  # decodable-am-diag-gmm.h:96
+            ac = np.float32(-1) * (scale * ll_b[u][col[int(m.id2pdf[tid])], t])  # decodable-am-diag-gmm.h:96
             terms[2 * t], terms[2 * t + 1] = w, ac
             st = int(g["nextstate"][a])
         fin = g["final"][s0 + st]

@@ -46,13 +46,17 @@ def test_config5_em_pass_properties(ctx, stress, monkeypatch):
     m, gc, ut, cost, dm, tm, us = stress
     N = int(ut.frame_off[-1])
     assert N > 250000
-    # ---- K1: two tilings, one answer ----
+    # ---- K1: two fp32-MFMA tilings, one answer; the bf16x3 form (the default) checked against fp64 below ----
+    monkeypatch.setenv("KHG_K1", "pdf")
     us.loglikes(dm)
     ll = us.download_loglikes()
     monkeypatch.setenv("KHG_K1", "utt")
     us.loglikes(dm)
     ll_utt = us.download_loglikes()
     monkeypatch.delenv("KHG_K1")
+    us.loglikes(dm)
+    ll_b = us.download_loglikes()
+    assert max(float(np.abs(x - y).max()) for x, y in zip(ll, ll_b)) < 5e-3 and all(np.isfinite(x).all() for x in ll_b)
     worst = max(float(np.max(np.abs(x - y) / np.spacing(np.abs(x)))) for x, y in zip(ll, ll_utt))
     same = sum(int((x == y).sum()) for x, y in zip(ll, ll_utt)) / sum(x.size for x in ll)
     assert worst <= 2.0 and same > 0.5, (worst, same)
@@ -63,7 +67,7 @@ def test_config5_em_pass_properties(ctx, stress, monkeypatch):
     for u in (0, U // 2, U - 1):
         pl = pdfs[poff[u]: poff[u + 1]][:6]
         exact, bound = exact_loglikes(m, gc, ut.feats[ut.frame_off[u]: ut.frame_off[u + 1]], pl)
-        assert (np.abs(ll[u][:6] - exact) <= 1e-5 + 1e-6 * bound).all()
+        assert (np.abs(ll[u][:6] - exact) <= 1e-5 + 1e-6 * bound).all() and (np.abs(ll_b[u][:6] - exact) <= 1e-5 + 1e-6 * bound).all()
 
     # ---- K2 ----
     us.loglikes(dm, reachable_only=True)
@@ -73,10 +77,10 @@ def test_config5_em_pass_properties(ctx, stress, monkeypatch):
     for u in rng.choice(U, size=60, replace=False):
         sl = slice(ut.frame_off[u], ut.frame_off[u + 1])
         pl = pdfs[poff[u]: poff[u + 1]]
-        ok, c = token_path_cost(ut.graphs, u, res["ali"][sl], ll[u], pl, cost, m.id2pdf, 0.1)
+        ok, c = token_path_cost(ut.graphs, u, res["ali"][sl], ll_b[u], pl, cost, m.id2pdf, 0.1)
         assert ok, f"utterance {u}: not an accepting path"
         assert -c / 0.1 == pytest.approx(float(res["like"][u]), rel=2e-6)
-        ok_ref, c_ref = token_path_cost(ut.graphs, u, ut.ref_ali[sl], ll[u], pl, cost, m.id2pdf, 0.1)
+        ok_ref, c_ref = token_path_cost(ut.graphs, u, ut.ref_ali[sl], ll_b[u], pl, cost, m.id2pdf, 0.1)
         assert ok_ref and c <= c_ref + 1e-9
 
     # ---- K3 (block form: 128 Gaussians per pdf, D = 80) ----
