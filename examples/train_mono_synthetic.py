@@ -104,8 +104,8 @@ def main():
     cfg = khg.AlignConfig(beam=6.0, retry_beam=40.0, careful=False)
     for i in range(args.iters):
         if i in realign:
-            khg.gmm_boost_silence(am, transition_model, [SIL], boost=1.0)
-            r = khg.gmm_align_compiled_batch(am, transition_model, names, train_graphs, feats, cfg, acoustic_scale=0.1,
+            am_b = khg.gmm_boost_silence(am, transition_model, [SIL], boost=1.0)    # a boosted COPY aligns; `am` is what gets updated
+            r = khg.gmm_align_compiled_batch(am_b, transition_model, names, train_graphs, feats, cfg, acoustic_scale=0.1,
                                              transition_scale=1.0, self_loop_scale=0.1)
             ali = [a if a else old for a, old in zip(r["alignment"], ali)]
             print(f"pass {i}: aligned {r['num_done']} utterances, {r['num_error']} errors, {r['num_retried']} retried, "

@@ -219,6 +219,9 @@ typedef struct {
   float min_gaussian_occupancy;       /* 10 */
   double min_variance;                /* 1e-3 */
   int32_t remove_low_count_gaussians; /* 1 */
+  /* variance_floor_vector (csrc/mle-diag-gmm.h:26-28, used at csrc/mle-diag-gmm.cc:311-322): per-dimension floor, host
+   * pointer to `dim` doubles, NULL = not supplied (then min_variance floors every dimension) */
+  const double *variance_floor_vector;
 } khg_mle_options;
 void khg_mle_options_default(khg_mle_options *o);
 
@@ -233,6 +236,14 @@ int khg_mle_am_diag_gmm_update(const khg_mle_options *o, int32_t num_pdfs, int32
                                float *inv_vars, int32_t *new_gauss_off, float *objf_change,
                                float *count, int32_t *floored_elems, int32_t *floored_gauss,
                                int32_t *removed);
+
+/* DiagGmm::Merge (csrc/diag-gmm.cc:557-759, MergedComponentsLogdet :761-778) on one pdf's flat arrays: greedy merging of
+ * the pair whose union loses the least likelihood, down to target_components (1: the global mean and variance); arrays are
+ * compacted in place, gconsts recomputed; history_out (may be NULL) receives the merged pairs (kept, removed) in order --
+ * what python/csrc/diag-gmm.cc:79-85 returns from DiagGmm.merge.  AmDiagGmm::MergeByCount (csrc/am-diag-gmm.cc:91-108) =
+ * this per pdf with the targets of GetSplitTargets.  Host only. */
+int khg_diag_gmm_merge(int32_t *num_gauss, int32_t dim, int32_t target_components, float *weights, float *gconsts,
+                       float *means_invvars, float *inv_vars, int32_t *history_out, int32_t *num_history_out);
 
 /* ---- K4: the same M-step on the device ---------------------------------- */
 /* MleAmDiagGmmUpdate (csrc/mle-am-diag-gmm.cc:153-202; per pdf MleDiagGmmUpdate,

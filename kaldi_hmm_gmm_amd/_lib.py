@@ -64,6 +64,7 @@ class MleOptionsC(C.Structure):
         ("min_gaussian_occupancy", C.c_float),
         ("min_variance", C.c_double),
         ("remove_low_count_gaussians", C.c_int32),
+        ("variance_floor_vector", C.POINTER(C.c_double)),
     ]
 
 
@@ -121,6 +122,7 @@ SIGNATURES = {
         [C.POINTER(MleOptionsC), C.c_int32, C.c_int32, c_i32p, c_f64p, c_f64p, c_f64p, C.c_uint16, C.c_uint16, c_f32p,
          c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p],
     ),
+    "khg_diag_gmm_merge": (C.c_int, [c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p]),
     "khg_model_set_weights": (C.c_int, [vp, vp, c_f32p]),
     "khg_model_mle_update": (C.c_int, [vp, vp, vp, C.POINTER(MleOptionsC), C.c_uint16, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p]),
     "khg_model_num_gauss": (C.c_int, [vp, C.POINTER(C.c_int64), c_i32p]),

@@ -1439,6 +1439,15 @@ extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* 
   a.w = m->weights_d; a.gc = m->gconsts_d; a.miv = m->miv_d; a.iv = m->iv_d;
   a.res = res_d;
   a.min_w = o->min_gaussian_weight; a.min_occ = o->min_gaussian_occupancy; a.min_var = o->min_variance;
+  double* floor_d = nullptr;
+  a.var_floor = nullptr;
+  if (o->variance_floor_vector) {
+    std::vector<double> fv(o->variance_floor_vector, o->variance_floor_vector + D);
+    int rcf = dev_upload(ctx, &floor_d, fv);
+    if (!rcf) { hipError_t ef = hipStreamSynchronize(ctx->stream); if (ef != hipSuccess) rcf = khg_set_error(KHG_E_HIP, hipGetErrorString(ef)); }
+    if (rcf) { DEVFREE(res_d); DEVFREE(floor_d); return rcf; }
+    a.var_floor = floor_d;
+  }
   a.remove_low = o->remove_low_count_gaussians; a.flags = flags;
   {
     KernelTimer kt(ctx, "k4_mle_update");
@@ -1448,7 +1457,7 @@ extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* 
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(res.data(), res_d, sizeof(K4Res) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  DEVFREE(res_d);
+  DEVFREE(res_d); DEVFREE(floor_d);
   if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
   // totals in pdf order, float, as MleAmDiagGmmUpdate adds them (csrc/mle-am-diag-gmm.cc:177-193)
   float tot_obj = 0.0f, tot_count = 0.0f;

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <cstdlib>
 #include <string>
 #include <thread>
@@ -89,8 +90,10 @@ bool MleUpdateOne(const khg_mle_options& o, int D, const double* occ, const doub
         if (!(flags & kMeans))
           for (int d = 0; d < D; ++d) { const double dm = old_mean[d] - mu[d]; var[d] += dm * dm; }
         int floored = 0;
-        for (int d = 0; d < D; ++d)
-          if (var[d] < o.min_variance) { var[d] = o.min_variance; ++floored; }
+        for (int d = 0; d < D; ++d) {   // csrc/mle-diag-gmm.cc:311-333: the floor vector when supplied, else min_variance
+          const double fl = o.variance_floor_vector ? o.variance_floor_vector[d] : o.min_variance;
+          if (var[d] < fl) { var[d] = fl; ++floored; }
+        }
         if (floored) { res->floored_elems += floored; ++res->floored_gauss; }
         for (int d = 0; d < D; ++d) nvars[(size_t)i * D + d] = var[d];
       }
@@ -134,7 +137,7 @@ bool MleUpdateOne(const khg_mle_options& o, int D, const double* occ, const doub
 }  // namespace
 
 extern "C" void khg_mle_options_default(khg_mle_options* o) {
-  o->min_gaussian_weight = 1.0e-05f; o->min_gaussian_occupancy = 10.0f; o->min_variance = 0.001; o->remove_low_count_gaussians = 1;
+  o->min_gaussian_weight = 1.0e-05f; o->min_gaussian_occupancy = 10.0f; o->min_variance = 0.001; o->remove_low_count_gaussians = 1; o->variance_floor_vector = nullptr;
 }
 
 extern "C" int khg_compute_gconsts(int32_t P, int32_t D, const int32_t* gauss_off, const float* weights,
@@ -293,5 +296,118 @@ extern "C" int khg_scaled_trans_cost(int32_t num_tids, const float* log_probs, c
     }
     out[tid] = -s;
   }
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// DiagGmm::Merge (csrc/diag-gmm.cc:557-759).  Second-order statistics per component (mean, E[x^2]) normalised by the
+// weight; the likelihood change of merging (i, j) is w_sum * logdet(merged) - w_i logdet_i - w_j logdet_j with
+// logdet = -1/2 sum log var; the pair with the LARGEST change (least loss) is merged, strict '>' over the lower triangle
+// in (i, j < i) order, so ties go to the first pair scanned.
+namespace {
+struct MergeState {
+  int G, D;
+  std::vector<float> mean, m2, logdet, delta;   // delta: G x G, symmetric once touched
+  std::vector<char> gone;
+  float* w;
+  float PairLogdet(int i, int j) const {          // MergedComponentsLogdet (:761-778)
+    const float w1 = w[i], w2 = w[j], ratio = w2 / w1, scale = w1 / (w1 + w2);
+    const float *f1 = &mean[(size_t)i * D], *f2 = &mean[(size_t)j * D], *s1 = &m2[(size_t)i * D], *s2 = &m2[(size_t)j * D];
+    float acc = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      const float mu = (f1[d] + f2[d] * ratio) * scale;
+      acc += std::log((s1[d] + s2[d] * ratio) * scale - mu * mu);
+    }
+    return static_cast<float>(-0.5 * acc);
+  }
+  float Delta(int i, int j) const { const float w1 = w[i], w2 = w[j]; return (w1 + w2) * PairLogdet(i, j) - w1 * logdet[i] - w2 * logdet[j]; }
+};
+}  // namespace
+
+extern "C" int khg_diag_gmm_merge(int32_t* num_gauss, int32_t D, int32_t target, float* weights, float* gconsts, float* miv,
+                                  float* iv, int32_t* history, int32_t* num_history) {
+  if (!num_gauss || !weights || !gconsts || !miv || !iv || D <= 0) return khg_set_error(KHG_E_ARG, "khg_diag_gmm_merge: bad arguments");
+  const int G = *num_gauss;
+  if (num_history) *num_history = 0;
+  if (target <= 0 || G < target)
+    return khg_set_error(KHG_E_RUNTIME, "Invalid argument for target number of Gaussians (=" + std::to_string(target) + "), #Gauss = " + std::to_string(G));
+  if (G == target) return KHG_OK;
+  MergeState st;
+  st.G = G; st.D = D; st.w = weights;
+  st.mean.resize((size_t)G * D); st.m2.resize((size_t)G * D);
+  for (size_t k = 0; k < (size_t)G * D; ++k) {
+    const float var = 1.0f / iv[k], mu = miv[k] * var;
+    st.mean[k] = mu; st.m2[k] = var + mu * mu;
+  }
+  int nb = 0;
+  if (target == 1) {   // :571-611: one Gaussian with the mixture's global mean and variance
+    std::vector<float> gm((size_t)D, 0.0f), gs((size_t)D, 0.0f);
+    for (int d = 0; d < D; ++d)
+      for (int g = 0; g < G; ++g) { gm[d] += weights[g] * st.mean[(size_t)g * D + d]; gs[d] += weights[g] * st.m2[(size_t)g * D + d]; }
+    float wsum = 0.0f;
+    for (int g = 0; g < G; ++g) wsum += weights[g];
+    weights[0] = wsum;
+    if (!(std::fabs(wsum - 1.0f) <= 1e-6f * (std::fabs(wsum) + 1.0f))) {   // !ApproxEqual(w, 1, 1e-6): ":rescaling" as the reference writes it
+      for (int d = 0; d < D; ++d) { gm[d] *= weights[0]; gs[d] *= weights[0]; }
+      weights[0] = 1.0f;
+    }
+    for (int d = 0; d < D; ++d) { iv[d] = 1.0f / (gs[d] - gm[d] * gm[d]); miv[d] = gm[d] * iv[d]; }
+    *num_gauss = 1;
+    if (!ComputeGconstsOne(1, D, weights, iv, miv, gconsts, &nb)) return khg_set_error(KHG_E_RUNTIME, "At component 0, not a number in gconst computation");
+    return KHG_OK;
+  }
+  st.logdet.resize((size_t)G); st.delta.assign((size_t)G * G, 0.0f); st.gone.assign((size_t)G, 0);
+  for (int g = 0; g < G; ++g) {
+    float acc = 0.0f;
+    for (int d = 0; d < D; ++d) acc += std::log(iv[(size_t)g * D + d]);
+    st.logdet[g] = 0.5f * acc;
+  }
+  for (int i = 1; i < G; ++i)
+    for (int j = 0; j < i; ++j) st.delta[(size_t)i * G + j] = st.Delta(i, j);
+  int nh = 0;
+  for (int step = G; step > target; --step) {
+    float best = -std::numeric_limits<float>::max();
+    int bi = -1, bj = -1;
+    for (int i = 1; i < G; ++i) {
+      if (st.gone[i]) continue;
+      const float* row = &st.delta[(size_t)i * G];
+      for (int j = 0; j < i; ++j)
+        if (!st.gone[j] && row[j] > best) { best = row[j]; bi = i; bj = j; }
+    }
+    if (bi < 0 || bj < 0) return khg_set_error(KHG_E_RUNTIME, "max_i != max_j && max_i != -1 && max_j != -1 assertion failed");
+    if (history) { history[nh] = bi; history[nh + 1] = bj; }
+    nh += 2;
+    const float w1 = weights[bi], w2 = weights[bj], w_sum = w1 + w2, ratio = w2 / w1;
+    float ld = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      const size_t a = (size_t)bi * D + d, b = (size_t)bj * D + d;
+      st.mean[a] = (st.mean[a] + ratio * st.mean[b]) * w1 / w_sum;
+      st.m2[a] = (st.m2[a] + ratio * st.m2[b]) * w1 / w_sum;
+      iv[a] = 1.0f / (st.m2[a] - st.mean[a] * st.mean[a]);
+      miv[a] = st.mean[a] * iv[a];
+      ld += std::log(iv[a]);
+    }
+    weights[bi] = w_sum;
+    st.logdet[bi] = 0.5f * ld;
+    st.gone[bj] = 1;
+    for (int j = 0; j < G; ++j) {
+      if (j == bi || st.gone[j]) continue;
+      const float t = st.Delta(bi, j);
+      st.delta[(size_t)bi * G + j] = t; st.delta[(size_t)j * G + bi] = t;
+    }
+  }
+  int kept = 0;
+  for (int i = 0; i < G; ++i) {
+    if (st.gone[i]) continue;
+    if (kept != i) {
+      weights[kept] = weights[i];
+      std::memmove(miv + (size_t)kept * D, miv + (size_t)i * D, sizeof(float) * D);
+      std::memmove(iv + (size_t)kept * D, iv + (size_t)i * D, sizeof(float) * D);
+    }
+    ++kept;
+  }
+  *num_gauss = kept;
+  if (num_history) *num_history = nh;
+  if (!ComputeGconstsOne(kept, D, weights, iv, miv, gconsts, &nb)) return khg_set_error(KHG_E_RUNTIME, "not a number in gconst computation");
   return KHG_OK;
 }

@@ -231,6 +231,24 @@ class DiagGmm:
         self._gconsts = np.zeros(target_components, f32)
         self.compute_gconsts()
 
+    def merge(self, target_components: int) -> List[int]:
+        """DiagGmm::Merge (csrc/diag-gmm.cc:557-759) through the library's host entry point khg_diag_gmm_merge; returns the
+        merge history [kept_0, removed_0, kept_1, removed_1, ...] like python/csrc/diag-gmm.cc:79-85."""
+        import ctypes as C
+        from ._lib import check, lib, ptr
+        G = C.c_int32(self.num_gauss)
+        w = np.array(self._weights, f32); miv = np.array(self._means_invvars, f32); iv = np.array(self._inv_vars, f32)
+        gc = np.zeros(self.num_gauss, f32)
+        hist = np.zeros(2 * max(self.num_gauss, 1), np.int32)
+        nh = C.c_int32()
+        check(lib.khg_diag_gmm_merge(C.byref(G), self.dim, int(target_components), ptr(w, C.c_float), ptr(gc, C.c_float),
+                                     ptr(miv, C.c_float), ptr(iv, C.c_float), ptr(hist, C.c_int32), C.byref(nh)))
+        if G.value != self.num_gauss:
+            g = G.value
+            self._weights, self._means_invvars, self._inv_vars, self._gconsts = w[:g].copy(), miv[:g].copy(), iv[:g].copy(), gc[:g].copy()
+            self._valid_gconsts = True
+        return hist[: nh.value].tolist()
+
     def perturb(self, perturb_factor: float, randn=None):   # csrc/diag-gmm.cc:463-484
         rng = randn or (lambda shape: np.random.standard_normal(shape).astype(f32))
         rv = np.asarray(rng(self._means_invvars.shape), f32) * np.sqrt(self._inv_vars)
@@ -349,8 +367,13 @@ class AmDiagGmm:
             if p.num_gauss < targets[i]:
                 p.split(targets[i], perturb_factor, randn=randn)
 
-    def merge_by_count(self, state_occs, target_components: int, power: float, min_count: float):
-        raise KhgError("AmDiagGmm.merge_by_count (DiagGmm::Merge) is outside the accelerated EM path")
+    def merge_by_count(self, state_occs, target_components: int, power: float, min_count: float):   # csrc/am-diag-gmm.cc:91-108
+        from .mle import get_split_targets
+        targets = get_split_targets(state_occs, target_components, power, min_count)
+        for i, p in enumerate(self._pdfs):
+            t = 1 if targets[i] == 0 else targets[i]      # can't merge below 1
+            if p.num_gauss > t:
+                p.merge(t)
 
     # ---- flat ragged view used by the device path ----
     def flat(self):

@@ -87,7 +87,8 @@ def get_split_targets(state_occs, target_components: int, power: float, min_coun
 
 class MleDiagGmmOptions:   # csrc/mle-diag-gmm.h:23-45
     def __init__(self, min_gaussian_weight: float = 1.0e-05, min_gaussian_occupancy: float = 10.0,
-                 min_variance: float = 0.001, remove_low_count_gaussians: bool = True):
+                 min_variance: float = 0.001, remove_low_count_gaussians: bool = True, variance_floor_vector=None):
+        self.variance_floor_vector = variance_floor_vector     # per-dimension floor, float64 [dim] (csrc/mle-diag-gmm.h:26-28)
         self.min_gaussian_weight = min_gaussian_weight
         self.min_gaussian_occupancy = min_gaussian_occupancy
         self.min_variance = min_variance
@@ -99,8 +100,13 @@ class MleDiagGmmOptions:   # csrc/mle-diag-gmm.h:23-45
                 f"remove_low_count_gaussians={'True' if self.remove_low_count_gaussians else 'False'})")
 
     def _c(self):
-        return _lib.MleOptionsC(self.min_gaussian_weight, self.min_gaussian_occupancy, self.min_variance,
-                                int(self.remove_low_count_gaussians))
+        o = _lib.MleOptionsC(self.min_gaussian_weight, self.min_gaussian_occupancy, self.min_variance,
+                             int(self.remove_low_count_gaussians), None)
+        if self.variance_floor_vector is not None and len(self.variance_floor_vector):
+            import ctypes as C
+            self._vfv = np.ascontiguousarray(self.variance_floor_vector, np.float64)     # kept alive by the options object
+            o.variance_floor_vector = self._vfv.ctypes.data_as(C.POINTER(C.c_double))
+        return o
 
 
 class AccumDiagGmm:

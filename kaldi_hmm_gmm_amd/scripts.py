@@ -152,11 +152,24 @@ def gmm_est(am_gmm: AmDiagGmm, gmm_accs: AccumAmDiagGmm, transition_model: Trans
     return info
 
 
-def gmm_boost_silence(am_gmm: AmDiagGmm, transition_model: TransitionModel, silence_phones: List[int], boost: float = 1.5):
-    """scripts/gmm_boost_silence.py:10-45: scale the weights of the silence phones' pdfs."""
+def gmm_boost_silence(am_gmm: AmDiagGmm, transition_model: TransitionModel, silence_phones: List[int], boost: float = 1.5,
+                      verbose: bool = False) -> AmDiagGmm:
+    """scripts/gmm_boost_silence.py:10-45: a COPY of am_gmm with the weights of the silence phones' pdfs scaled by `boost`
+    (gconsts recomputed); the argument is left untouched, as in the reference, whose recipe does
+    `am = gmm_boost_silence(am_gmm=am, ...)` (egs/yesno/train.py:158).  silence_phones is sorted in place like there."""
     from .transition_model import get_pdfs_for_phones
-    _, pdfs = get_pdfs_for_phones(transition_model, sorted(silence_phones))
+    if len(silence_phones) == 0:
+        raise KhgError("gmm_boost_silence: no silence phones")
+    silence_phones.sort()
+    is_unique, pdfs = get_pdfs_for_phones(transition_model, silence_phones)
+    if not is_unique and verbose:
+        print("The pdfs for the silence phones may be shared by other phones (note: this probably does not matter.)")
+    dgm = AmDiagGmm()
+    dgm.copy_from_am_diag_gmm(am_gmm)
     for pdf in pdfs:
-        g = am_gmm.get_pdf(pdf)
+        g = dgm.get_pdf(pdf)
         g.set_weights(g.weights * np.float32(boost))
         g.compute_gconsts()
+    if verbose:
+        print("Boosted weights for", len(pdfs), "pdfs, by factor of", boost)
+    return dgm

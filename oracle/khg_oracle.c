@@ -642,6 +642,113 @@ static void decoder_free(Decoder *d) {
   free(d->buckets); free((void *)d->queue); free(d->tmp_array);
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* diag-gmm.cc:761-778 MergedComponentsLogdet */
+static float merged_logdet(int32_t D, float w1, float w2, const float *f1, const float *f2, const float *s1,
+                           const float *s2) {
+  float w_sum = w1 + w2, r = w2 / w1, q = w1 / w_sum, acc = 0.0f;
+  for (int32_t d = 0; d < D; ++d) {
+    float tm = (f1[d] + f2[d] * r) * q;
+    float tv = (s1[d] + s2[d] * r) * q - tm * tm;
+    acc += logf(tv);
+  }
+  return (float)(-0.5 * acc); /* :774 double literal x float sum, stored to float */
+}
+
+/* diag-gmm.cc:557-759 DiagGmm::Merge */
+int orc_diag_gmm_merge(int32_t *G_io, int32_t D, int32_t target, float *weights, float *gconsts, float *miv, float *iv,
+                       int32_t *history, int32_t *num_history) {
+  const int32_t G = *G_io;
+  if (num_history) *num_history = 0;
+  if (target <= 0 || G < target) return ORC_ERR_ARG;   /* :558-561 KHG_ERR */
+  if (G == target) return ORC_OK;                      /* :563-567 */
+  float *vars = (float *)malloc(sizeof(float) * (size_t)G * D), *means = (float *)malloc(sizeof(float) * (size_t)G * D);
+  if (!vars || !means) { free(vars); free(means); return ORC_ERR_NOMEM; }
+  for (size_t i = 0; i < (size_t)G * D; ++i) {         /* :573-578 / :617-623 */
+    vars[i] = 1.0f / iv[i];
+    means[i] = miv[i] * vars[i];
+    vars[i] = vars[i] + means[i] * means[i];
+  }
+  if (target == 1) {                                   /* :571-611 global mean and variance */
+    float wsum = 0.0f;
+    for (int32_t d = 0; d < D; ++d) {
+      float a = 0.0f, b = 0.0f;
+      for (int32_t g = 0; g < G; ++g) { a += weights[g] * means[(size_t)g * D + d]; b += weights[g] * vars[(size_t)g * D + d]; }
+      miv[d] = a; iv[d] = b;
+    }
+    for (int32_t g = 0; g < G; ++g) wsum += weights[g];
+    weights[0] = wsum;
+    if (!(fabsf(wsum - 1.0f) <= 1e-6f * (fabsf(wsum) + 1.0f))) {   /* ApproxEqual(w, 1, 1e-6), kaldi-math.h */
+      for (int32_t d = 0; d < D; ++d) { miv[d] *= weights[0]; iv[d] *= weights[0]; }   /* :601-603 (as written: times, not divided by) */
+      weights[0] = 1.0f;
+    }
+    for (int32_t d = 0; d < D; ++d) { iv[d] = 1.0f / (iv[d] - miv[d] * miv[d]); miv[d] = miv[d] * iv[d]; }
+    *G_io = 1;
+    free(vars); free(means);
+    return orc_compute_gconsts(1, D, weights, iv, miv, gconsts, NULL);
+  }
+  char *disc = (char *)calloc((size_t)G, 1);
+  float *logdet = (float *)malloc(sizeof(float) * (size_t)G), *dl = (float *)calloc((size_t)G * G, sizeof(float));
+  if (!disc || !logdet || !dl) { free(vars); free(means); free(disc); free(logdet); free(dl); return ORC_ERR_NOMEM; }
+  for (int32_t g = 0; g < G; ++g) {                    /* :620 logdet = 0.5 * sum log inv_vars */
+    float a = 0.0f;
+    for (int32_t d = 0; d < D; ++d) a += logf(iv[(size_t)g * D + d]);
+    logdet[g] = 0.5f * a;
+  }
+  for (int32_t i = 0; i < G; ++i)                      /* :636-648 */
+    for (int32_t j = 0; j < i; ++j) {
+      float w1 = weights[i], w2 = weights[j], w_sum = w1 + w2;
+      float ml = merged_logdet(D, w1, w2, means + (size_t)i * D, means + (size_t)j * D, vars + (size_t)i * D, vars + (size_t)j * D);
+      dl[(size_t)i * G + j] = w_sum * ml - w1 * logdet[i] - w2 * logdet[j];
+    }
+  int32_t nh = 0;
+  for (int32_t removed = 0; removed < G - target; ++removed) {   /* :651-727 */
+    float best = -FLT_MAX;
+    int32_t mi = -1, mj = -1;
+    for (int32_t i = 0; i < G; ++i) {
+      if (disc[i]) continue;
+      for (int32_t j = 0; j < i; ++j) {
+        if (disc[j]) continue;
+        if (dl[(size_t)i * G + j] > best) { best = dl[(size_t)i * G + j]; mi = i; mj = j; }
+      }
+    }
+    if (mi == mj || mi < 0 || mj < 0) { free(vars); free(means); free(disc); free(logdet); free(dl); return ORC_ERR_ARG; }
+    if (history) { history[nh++] = mi; history[nh++] = mj; }
+    float w1 = weights[mi], w2 = weights[mj], w_sum = w1 + w2, r = w2 / w1;
+    float *mI = means + (size_t)mi * D, *mJ = means + (size_t)mj * D, *vI = vars + (size_t)mi * D, *vJ = vars + (size_t)mj * D;
+    float ld = 0.0f;
+    for (int32_t d = 0; d < D; ++d) {
+      mI[d] = (mI[d] + r * mJ[d]) * w1 / w_sum;        /* :680-681 ((a + r b) w1) / w_sum */
+      vI[d] = (vI[d] + r * vJ[d]) * w1 / w_sum;
+      iv[(size_t)mi * D + d] = 1.0f / (vI[d] - mI[d] * mI[d]);
+      miv[(size_t)mi * D + d] = mI[d] * iv[(size_t)mi * D + d];
+      ld += logf(iv[(size_t)mi * D + d]);
+    }
+    weights[mi] = w_sum;
+    logdet[mi] = 0.5f * ld;
+    disc[mj] = 1;
+    for (int32_t j = 0; j < G; ++j) {                  /* :709-726 */
+      if (j == mi || disc[j]) continue;
+      float a1 = weights[mi], a2 = weights[j], as = a1 + a2;
+      float ml = merged_logdet(D, a1, a2, mI, means + (size_t)j * D, vI, vars + (size_t)j * D);
+      float t = as * ml - a1 * logdet[mi] - a2 * logdet[j];
+      dl[(size_t)mi * G + j] = t; dl[(size_t)j * G + mi] = t;
+    }
+  }
+  int32_t m = 0;                                       /* :729-757 compaction */
+  for (int32_t i = 0; i < G; ++i) {
+    if (disc[i]) continue;
+    weights[m] = weights[i];
+    if (m != i) { memmove(miv + (size_t)m * D, miv + (size_t)i * D, sizeof(float) * D); memmove(iv + (size_t)m * D, iv + (size_t)i * D, sizeof(float) * D); }
+    ++m;
+  }
+  *G_io = m;
+  if (num_history) *num_history = nh;
+  free(vars); free(means); free(disc); free(logdet); free(dl);
+  return orc_compute_gconsts(m, D, weights, iv, miv, gconsts, NULL);
+}
+
 /* ---- test hooks onto the HashList restatement above (the decoder's own code, no second copy), so that
  * tests/test_oracle_pins.py can replay the reference's csrc/hash-list-test.cc against it.  Values are carried in
  * the Token* slot as integers. ---- */
@@ -955,7 +1062,7 @@ int orc_acc_stats_ali(const orc_model *m, const int32_t *id2pdf, int32_t num_tid
 /* ------------------------------------------------------------------------- */
 void orc_mle_opts_default(orc_mle_opts *o) {
   o->min_gaussian_weight = 1.0e-05f; o->min_gaussian_occupancy = 10.0f;
-  o->min_variance = 0.001; o->remove_low_count_gaussians = 1;
+  o->min_variance = 0.001; o->remove_low_count_gaussians = 1; o->variance_floor_vector = NULL;
 }
 
 /* model-common.cc:72-85 */
@@ -1043,7 +1150,9 @@ int orc_mle_diag_gmm_update(const orc_mle_opts *o, int32_t *G_io, int32_t D, con
         }
         int32_t floored = 0;
         for (int32_t d = 0; d < D; ++d)
-          if (var[d] < o->min_variance) { var[d] = o->min_variance; ++floored; } /* :324-330 */
+          if (o->variance_floor_vector) {              /* :311-322 */
+            if (var[d] < o->variance_floor_vector[d]) { var[d] = o->variance_floor_vector[d]; ++floored; }
+          } else if (var[d] < o->min_variance) { var[d] = o->min_variance; ++floored; } /* :324-330 */
         if (floored != 0) { elements_floored += floored; ++gauss_floored; }
         for (int32_t d = 0; d < D; ++d) nvars[(size_t)i * D + d] = var[d];
       }

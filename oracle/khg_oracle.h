@@ -174,6 +174,7 @@ typedef struct {
   float min_gaussian_occupancy;   /* 10 */
   double min_variance;            /* 1e-3 */
   int32_t remove_low_count_gaussians; /* 1 */
+  const double *variance_floor_vector; /* mle-diag-gmm.h:26-28: per-dimension floor, NULL = not supplied */
 } orc_mle_opts;
 void orc_mle_opts_default(orc_mle_opts *o);
 
@@ -187,6 +188,12 @@ int orc_mle_diag_gmm_update(const orc_mle_opts *o, int32_t *G, int32_t D, const 
                             uint16_t flags, float *weights, float *gconsts, float *means_invvars,
                             float *inv_vars, float *obj_change, float *count,
                             int32_t *floored_elems, int32_t *floored_gauss, int32_t *removed);
+
+/* diag-gmm.cc:557-759 DiagGmm::Merge (+ MergedComponentsLogdet :761-778): arrays updated in place, *G shrinks to
+ * target_components; history[2 * (G_in - target)] receives the merged pairs (max_i, max_j) in order (NULL allowed).
+ * Sums run over d (and over components for the global mean / variance) in index order, float arithmetic as written. */
+int orc_diag_gmm_merge(int32_t *G, int32_t D, int32_t target_components, float *weights, float *gconsts,
+                       float *means_invvars, float *inv_vars, int32_t *history, int32_t *num_history);
 
 /* mle-diag-gmm.cc:479-499 */
 float orc_ml_objective(int32_t G, int32_t D, const float *gconsts, const float *means_invvars,

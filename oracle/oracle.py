@@ -52,7 +52,7 @@ class Accs(C.Structure):
 
 class MleOpts(C.Structure):
     _fields_ = [("min_gaussian_weight", C.c_float), ("min_gaussian_occupancy", C.c_float), ("min_variance", C.c_double),
-                ("remove_low_count_gaussians", C.c_int32)]
+                ("remove_low_count_gaussians", C.c_int32), ("variance_floor_vector", C.POINTER(C.c_double))]
 
 
 class OracleError(RuntimeError):
@@ -336,13 +336,27 @@ def em_pass_mt(m: "OModel", id2pdf, graphs: dict, frame_off, feats, first_utt=0,
     return frames.value, utts.value, failed.value, secs.value
 
 
+def diag_gmm_merge(weights, means_invvars, inv_vars, target_components):
+    """diag-gmm.cc:557-759 -> dict(weights, gconsts, means_invvars, inv_vars, history)."""
+    w = np.array(weights, f32, copy=True); miv = np.array(means_invvars, f32, copy=True)
+    iv = np.array(inv_vars, f32, copy=True); gc = np.zeros_like(w)
+    G = C.c_int32(w.shape[0]); nh = C.c_int32()
+    hist = np.zeros(2 * max(w.shape[0], 1), np.int32)
+    _chk(lib().orc_diag_gmm_merge(C.byref(G), miv.shape[1], int(target_components), _p(w, C.c_float), _p(gc, C.c_float),
+                                  _p(miv, C.c_float), _p(iv, C.c_float), _p(hist, C.c_int32), C.byref(nh)), "diag_gmm_merge")
+    g = G.value
+    return {"weights": w[:g], "gconsts": gc[:g], "means_invvars": miv[:g], "inv_vars": iv[:g], "history": hist[: nh.value].tolist()}
+
+
 def mle_diag_gmm_update(weights, means_invvars, inv_vars, occ, mean_acc, var_acc, acc_flags=0xF, flags=0x7,
-                        min_gaussian_weight=1e-5, min_gaussian_occupancy=10.0, min_variance=1e-3, remove=True):
+                        min_gaussian_weight=1e-5, min_gaussian_occupancy=10.0, min_variance=1e-3, remove=True,
+                        variance_floor_vector=None):
     w = np.array(weights, f32, copy=True); miv = np.array(means_invvars, f32, copy=True)
     iv = np.array(inv_vars, f32, copy=True); gc = np.zeros_like(w)
     occ = np.ascontiguousarray(occ, np.float64); ma = np.ascontiguousarray(mean_acc, np.float64)
     va = np.ascontiguousarray(var_acc, np.float64)
-    o = MleOpts(min_gaussian_weight, min_gaussian_occupancy, min_variance, int(remove))
+    vfv = None if variance_floor_vector is None else np.ascontiguousarray(variance_floor_vector, np.float64)
+    o = MleOpts(min_gaussian_weight, min_gaussian_occupancy, min_variance, int(remove), None if vfv is None else _p(vfv, C.c_double))
     G = C.c_int32(w.shape[0]); oc = C.c_float(); cnt = C.c_float(); fe = C.c_int32(); fg = C.c_int32(); rm = C.c_int32()
     _chk(lib().orc_mle_diag_gmm_update(C.byref(o), C.byref(G), miv.shape[1], _p(occ, C.c_double), _p(ma, C.c_double),
                                        _p(va, C.c_double), C.c_uint16(acc_flags), C.c_uint16(flags), _p(w, C.c_float),

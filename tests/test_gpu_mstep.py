@@ -203,3 +203,36 @@ def test_device_m_step_fixed_point_at_full_size(ctx):
     np.testing.assert_allclose(d["means_invvars"], m.means_invvars, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(d["gconsts"], gc, rtol=1e-5, atol=1e-4)
     assert abs(r["objf_change"]) <= 1e-7 * 6000.0 * P * 100
+
+
+def test_device_m_step_variance_floor_vector(ctx):
+    """MleDiagGmmOptions.variance_floor_vector (csrc/mle-diag-gmm.cc:311-322) through K4: per-dimension floors instead of
+    min_variance; parameters bit-exact vs the host M-step and the oracle, the same floored counters."""
+    P, Gmax, D = 17, 9, 23
+    rng = np.random.default_rng(91)
+    m = synth.make_model(P, Gmax, D, seed=77, ragged=True)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    occ, mean_acc, var_acc = _fake_accs(m, rng)
+    floor = rng.uniform(1e-3, 2.5, D)                  # the synthetic variances are U[0.35, 2.8]: a good share gets floored
+    opts = MleDiagGmmOptions(min_variance=1e9, variance_floor_vector=floor)     # min_variance must be ignored
+    h_off, h_w, h_gc, h_miv, h_iv, h_obj, h_cnt, h_fe, h_fg, h_rm = khg_mle._flat_update(
+        opts, m.gauss_off, occ, mean_acc, var_acc, 0x7, 7, m.weights, m.means_invvars, m.inv_vars)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    accs = DeviceAccs(ctx, dm, tm)
+    _upload(accs, occ, mean_acc, var_acc)
+    r = dm.mle_update(accs, opts, 7)
+    d = dm.download()
+    assert np.array_equal(d["gauss_off"], h_off) and r["removed"] == h_rm
+    assert r["floored_elements"] == h_fe > 100 and r["floored_gaussians"] == h_fg
+    assert float((1.0 / d["inv_vars"]).max()) < 1e6     # nothing was floored at min_variance = 1e9
+    for name, want in (("weights", h_w), ("inv_vars", h_iv), ("means_invvars", h_miv)):
+        np.testing.assert_array_equal(d[name], want, err_msg=name)
+    for p in range(P):
+        a0, b0 = int(m.gauss_off[p]), int(m.gauss_off[p + 1])
+        ref = orc.mle_diag_gmm_update(m.weights[a0:b0], m.means_invvars[a0:b0], m.inv_vars[a0:b0], occ[a0:b0], mean_acc[a0:b0],
+                                      var_acc[a0:b0], acc_flags=0xF, flags=7, min_variance=1e9, variance_floor_vector=floor)
+        a, b = int(h_off[p]), int(h_off[p + 1])
+        for name in ("weights", "inv_vars", "means_invvars"):
+            np.testing.assert_array_equal(d[name][a:b], ref[name], err_msg=f"pdf {p} {name} vs oracle")
+    assert _ulps(d["gconsts"], h_gc).max() <= GC_ULPS

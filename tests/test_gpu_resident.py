@@ -64,8 +64,11 @@ def test_resident_em_matches_per_call_scripts(ctx):
     for it, target in enumerate(mix):
         if it > 0:
             # boost: device vs scripts/gmm_boost_silence.py on a host copy (gconsts through logf: <= 4 ulps)
-            am_h = _clone(em.sync_host())
-            khg.gmm_boost_silence(am_h, tm_b, [ex.SIL], boost=1.25)
+            am_0 = _clone(em.sync_host())
+            w_before = am_0.flat()[2].copy()
+            am_h = khg.gmm_boost_silence(am_0, tm_b, [ex.SIL], boost=1.25)       # returns the boosted copy ...
+            assert am_h is not am_0 and np.array_equal(am_0.flat()[2], w_before)   # ... and leaves its argument alone
+            assert not np.array_equal(am_h.flat()[2], w_before)
             em.boost_silence([ex.SIL], boost=1.25)
             am_d = _clone(em.sync_host())
             _, gc_h, w_h, _, _ = am_h.flat()

@@ -341,3 +341,128 @@ def test_accum_diag_gmm_smoothing():
     assert np.allclose(c.variance_accumulator, v + 1.5 * (var + mu * mu))
     with pytest.raises(khg.KhgError):
         c.smooth_with_model(1.0, khg.DiagGmm(nmix=2, dim=4))
+
+
+def _set_gmm(w, mean, var):
+    g = khg.DiagGmm(nmix=len(w), dim=mean.shape[1])
+    g.set_weights(np.asarray(w, np.float32))
+    g.set_invvars((1 / var).astype(np.float32))        # python/tests/test_diag_gmm.py:248-250 order: means, then invvars
+    g.set_means(mean.astype(np.float32))
+    g.compute_gconsts()
+    return g
+
+
+def test_diag_gmm_merge_reference_known_answers():
+    """The reference's own checks of DiagGmm::Merge (python/tests/test_diag_gmm.py:239-263 and :265-299), against the product
+    (khg_diag_gmm_merge through DiagGmm.merge) AND the oracle restatement."""
+    rng = np.random.default_rng(7)
+    nmix, dim = 7, 6
+    w = rng.random(nmix).astype(np.float32); w /= w.sum()
+    mean = rng.random((nmix, dim)).astype(np.float32)
+    var = (rng.random((nmix, dim)) + 0.05).astype(np.float32)
+    g = _set_gmm(w, mean, var)
+    o = orc.diag_gmm_merge(g.weights, g.means_invvars, g.inv_vars, 1)
+    history = g.merge(target_components=1)
+    assert history == [] and o["history"] == []                         # :254
+    assert abs(g.weights[0] - 1) < 1e-6 and g.num_gauss == 1            # :255-256
+    exp_mean = (w.astype(np.float64)[None] @ mean.astype(np.float64))
+    exp_var = w.astype(np.float64)[None] @ (var.astype(np.float64) + mean.astype(np.float64) ** 2) - exp_mean ** 2
+    np.testing.assert_allclose(g.means, exp_mean, rtol=1e-5, atol=1e-8)   # :258-263 (torch.allclose defaults)
+    np.testing.assert_allclose(g.vars, exp_var, rtol=1e-4, atol=1e-6)
+    for k, arr in (("weights", g.weights), ("gconsts", g.gconsts), ("means_invvars", g.means_invvars), ("inv_vars", g.inv_vars)):
+        np.testing.assert_array_equal(arr, o[k], err_msg=k)
+    # case 2 (:265-299): components 2 and 0 are the closest pair; "2 comes first before 0 in history since we are building a
+    # lower triangular matrix in C++"
+    w = rng.random(4).astype(np.float32); w /= w.sum()
+    mean = np.array([[2, 2], [-10, -10], [1, 1], [-100, 100]], np.float32)
+    var = (rng.random((4, 2)) + 0.05).astype(np.float32)
+    g = _set_gmm(w, mean, var)
+    o = orc.diag_gmm_merge(g.weights, g.means_invvars, g.inv_vars, 3)
+    assert g.merge(target_components=3) == [2, 0] == o["history"] and g.num_gauss == 3
+    with pytest.raises(khg.KhgError):
+        g.merge(target_components=5)                                    # diag-gmm.cc:558-561
+    assert g.merge(target_components=3) == []                           # :563-567 nothing to do
+
+
+@pytest.mark.parametrize("G,D,target", [(9, 5, 4), (16, 13, 1), (16, 13, 15), (33, 40, 7), (5, 1, 2), (64, 40, 48)])
+def test_diag_gmm_merge_bit_exact_vs_oracle(G, D, target):
+    rng = np.random.default_rng(G * 100 + D)
+    w = rng.random(G).astype(np.float32); w /= w.sum()
+    mean = (2.0 * rng.standard_normal((G, D))).astype(np.float32)
+    mean[G // 2] = mean[0] + 0.01                                       # a nearly identical pair
+    var = (rng.random((G, D)) * 1.5 + 0.3).astype(np.float32)
+    g = _set_gmm(w, mean, var)
+    o = orc.diag_gmm_merge(g.weights, g.means_invvars, g.inv_vars, target)
+    hist = g.merge(target)
+    assert hist == o["history"] and len(hist) == (2 * (G - target) if target > 1 else 0) and g.num_gauss == target
+    for k, arr in (("weights", g.weights), ("gconsts", g.gconsts), ("means_invvars", g.means_invvars), ("inv_vars", g.inv_vars)):
+        np.testing.assert_array_equal(arr, o[k], err_msg=k)
+    assert abs(float(g.weights.sum()) - 1.0) < 1e-5
+    if target > 1:
+        assert all(hist[k] > hist[k + 1] for k in range(0, len(hist), 2))    # (max_i, max_j) pairs come from the lower triangle: j < i
+
+
+def test_am_diag_gmm_merge_by_count_and_gmm_est_mixdown():
+    """AmDiagGmm::MergeByCount (csrc/am-diag-gmm.cc:91-108): per-pdf targets from GetSplitTargets, never below 1."""
+    rng = np.random.default_rng(3)
+    am = _rand_am(rng, 5, 6, 4)
+    occs = np.array([500.0, 20.0, 0.0, 3000.0, 100.0], np.float32)
+    from kaldi_hmm_gmm_amd.mle import get_split_targets
+    targets = get_split_targets(occs, 14, 0.2, 20.0)
+    before = [am.get_pdf(p).num_gauss for p in range(5)]
+    am.merge_by_count(state_occs=occs, target_components=14, power=0.2, min_count=20.0)
+    after = [am.get_pdf(p).num_gauss for p in range(5)]
+    assert after == [min(b, max(t, 1)) for b, t in zip(before, targets)] and sum(after) < sum(before)
+    for p in range(5):
+        assert abs(float(am.get_pdf(p).weights.sum()) - 1.0) < 1e-5 and np.isfinite(am.get_pdf(p).gconsts).all()
+
+
+def test_m_step_variance_floor_vector_bit_exact_vs_oracle():
+    """MleDiagGmmOptions.variance_floor_vector (csrc/mle-diag-gmm.h:26-28, mle-diag-gmm.cc:311-322): per-dimension floors
+    replace min_variance; host C++ M-step == oracle bit for bit, floored counters included."""
+    rng = np.random.default_rng(15)
+    P, G, D = 3, 5, 6
+    am = _rand_am(rng, P, G, D)
+    accs = khg.AccumAmDiagGmm()
+    accs.init(am, khg.GmmUpdateFlags.kGmmAll)
+    for p in range(P):
+        a = accs._accs[p]
+        for _ in range(400):
+            x = (rng.standard_normal(D) * np.array([0.05, 1, 1, 0.2, 1, 3])).astype(np.float32)
+            post = rng.random(G).astype(np.float32); post /= post.sum()
+            a.accumulate_from_posteriors(x, post)
+    floor = np.array([0.5, 1e-4, 1e-4, 0.2, 1e-4, 1e-4], np.float64)    # dims 0 and 3 get floored, min_variance is ignored
+    opts = khg.MleDiagGmmOptions(min_variance=100.0, variance_floor_vector=floor)
+    ref = [orc.mle_diag_gmm_update(am.get_pdf(p).weights, am.get_pdf(p).means_invvars, am.get_pdf(p).inv_vars, accs._accs[p].occupancy,
+                                   accs._accs[p].mean_accumulator, accs._accs[p].variance_accumulator, acc_flags=accs._accs[p].flags,
+                                   flags=7, min_variance=100.0, variance_floor_vector=floor) for p in range(P)]
+    khg.mle_am_diag_gmm_update(opts, accs, khg.str_to_gmm_flags("mvw"), am)
+    for p in range(P):
+        g = am.get_pdf(p)
+        assert ref[p]["floored_elems"] == 2 * G and ref[p]["floored_gauss"] == G
+        for k, arr in (("weights", g.weights), ("gconsts", g.gconsts), ("means_invvars", g.means_invvars), ("inv_vars", g.inv_vars)):
+            np.testing.assert_array_equal(arr, ref[p][k], err_msg=f"pdf {p} {k}")
+        np.testing.assert_allclose(g.vars[:, 0], 0.5, rtol=1e-6)
+        np.testing.assert_allclose(g.vars[:, 3], 0.2, rtol=1e-6)
+        assert (g.vars[:, 5] > 1.0).all()
+
+
+def test_gmm_boost_silence_returns_a_boosted_copy():
+    """scripts/gmm_boost_silence.py:10-45 returns a NEW AmDiagGmm and leaves its argument untouched; the reference's recipe
+    does `am = gmm_boost_silence(am_gmm=am, ...)` (egs/yesno/train.py:158)."""
+    topo, tree, tm = _tm()
+    rng = np.random.default_rng(9)
+    am = _rand_am(rng, tm.num_pdfs, 3, 4)
+    w0 = [am.get_pdf(p).weights.copy() for p in range(am.num_pdfs)]
+    gc0 = [am.get_pdf(p).gconsts.copy() for p in range(am.num_pdfs)]
+    phones = [3, 1]
+    out = khg.gmm_boost_silence(am_gmm=am, transition_model=tm, silence_phones=phones, boost=1.5)
+    assert out is not am and isinstance(out, khg.AmDiagGmm) and phones == [1, 3]      # sorted in place, like the reference
+    _, pdfs = khg.get_pdfs_for_phones(tm, [1, 3])
+    for p in range(am.num_pdfs):
+        assert np.array_equal(am.get_pdf(p).weights, w0[p]) and np.array_equal(am.get_pdf(p).gconsts, gc0[p])
+        if p in pdfs:
+            np.testing.assert_array_equal(out.get_pdf(p).weights, w0[p] * np.float32(1.5))
+            np.testing.assert_allclose(out.get_pdf(p).gconsts, gc0[p] + np.log(1.5), rtol=1e-6, atol=1e-5)
+        else:
+            assert np.array_equal(out.get_pdf(p).weights, w0[p]) and np.array_equal(out.get_pdf(p).gconsts, gc0[p])
