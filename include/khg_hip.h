@@ -133,7 +133,7 @@ int khg_utts_set_pdf_list(khg_utts *u, int32_t n, const int32_t *pdfs_h);
 typedef struct {
   float beam;        /* AlignConfig (csrc/decoder-wrappers.h:23-37): 200 */
   float retry_beam;  /* 0 */
-  int32_t careful;   /* 0; graphs must have been built with khg_careful_graph by the caller */
+  int32_t careful;   /* 0; careful alignment = graphs passed through khg_careful_graph by the caller before khg_utts_create */
   float acoustic_scale;
   /* FasterDecoderOptions (csrc/faster-decoder.h:24-49); AlignUtteranceWrapper keeps defaults */
   int32_t max_active; /* INT32_MAX */
@@ -149,6 +149,18 @@ void khg_align_config_default(khg_align_config *c);
 #define KHG_ALIGN_RETRIED 2   /* num_retried++                                                 */
 #define KHG_ALIGN_EXACT_DP 4  /* info: produced by the exact-DP kernel under a beam certificate */
 #define KHG_ALIGN_FALLBACK 8  /* info: produced by the order-faithful FasterDecoder kernel     */
+
+/* ModifyGraphForCarefulAlignment (csrc/decoder-wrappers.cc:111-140: fst := Concat(fst, fst_rhs), fst_rhs = a copy of fst
+ * without final weights, entered through a new final start state by an epsilon arc) on ONE graph in the CSR-by-source
+ * layout of khg_utts_create (host arrays; nextstate graph-local).  OpenFst's Concat semantics: every final state s of the
+ * left copy loses its final weight w and gains an epsilon arc (0:0 / w) to the right copy's start, appended after its own
+ * arcs.  Result: 2 S + 1 states (left copy 0..S-1, right copy S..2S-1, the pre-initial state 2S, final with weight 0),
+ * 2 A + 1 + (#final states) arcs; the caller sizes the output arrays for that ([2S+2] arc_off, [2A+1+S] arc arrays,
+ * [2S+1] final).  An empty graph (num_states == 0) is returned unchanged.  Host only. */
+int khg_careful_graph(int32_t num_states, int32_t start, const int64_t *arc_off_h, const int32_t *ilabel_h,
+                      const int32_t *olabel_h, const float *weight_h, const int32_t *nextstate_h, const float *final_h,
+                      int32_t *out_num_states, int32_t *out_start, int64_t *out_arc_off_h, int32_t *out_ilabel_h,
+                      int32_t *out_olabel_h, float *out_weight_h, int32_t *out_nextstate_h, float *out_final_h);
 
 /* AlignUtteranceWrapper (csrc/decoder-wrappers.cc:16-108) + FasterDecoder (csrc/faster-decoder.cc)
  * + DecodableAmDiagGmmScaled (csrc/decodable-am-diag-gmm.h:83-103) for every utterance of the

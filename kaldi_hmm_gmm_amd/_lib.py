@@ -122,6 +122,8 @@ SIGNATURES = {
         [C.POINTER(MleOptionsC), C.c_int32, C.c_int32, c_i32p, c_f64p, c_f64p, c_f64p, C.c_uint16, C.c_uint16, c_f32p,
          c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p],
     ),
+    "khg_careful_graph": (C.c_int, [C.c_int32, C.c_int32, c_i64p, c_i32p, c_i32p, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_i64p, c_i32p,
+                                    c_i32p, c_f32p, c_i32p, c_f32p]),
     "khg_diag_gmm_merge": (C.c_int, [c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p]),
     "khg_model_set_weights": (C.c_int, [vp, vp, c_f32p]),
     "khg_model_mle_update": (C.c_int, [vp, vp, vp, C.POINTER(MleOptionsC), C.c_uint16, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p]),

@@ -375,6 +375,7 @@ struct khg_utts {
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
+  unsigned char* k2_gscratch_d = nullptr; size_t k2_gscratch_bytes = 0;   // K2 tables of graphs too large for LDS
   int32_t *ali_d = nullptr, *words_d = nullptr, *num_words_d = nullptr, *status_d = nullptr;
   float* like_d = nullptr;
   bool ali_valid = false;
@@ -577,7 +578,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
   DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
-  DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d);
+  DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
   DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d);
@@ -1007,14 +1008,29 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
                   std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), tb_bytes) + 64;
   size_t HB = std::max<size_t>(2 * S, 1000);
   size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
-  if (lds_dp > 160 * 1024 || lds_f > 160 * 1024)
-    return khg_set_error(KHG_E_UNSUPPORTED, "khg_align: decoding graph too large for the LDS-resident Viterbi kernels (" +
-                                                std::to_string(u->max_states) + " states, " + std::to_string(u->max_inarcs) + " arcs)");
-  const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
-                   : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
-  if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
-  if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-  {
+  // Graphs whose decoder tables exceed the 160 KB of LDS (a large decoding graph, not a training graph): the generic DP and
+  // the one-lane order-faithful decoder run with the same tables carved out of an HBM scratch slice per utterance.
+  const bool gmem = lds_dp > 160 * 1024 || lds_f > 160 * 1024;
+  a.gscratch = nullptr; a.gscratch_stride = 0;
+  if (gmem) {
+    // (the generic DP's carve-up: no register-resident path)
+    lds_dp = 16 * S + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
+             std::max<size_t>(4 * K2_SB * (max_npdf | 1), (K2_FB + 1) * ((S + 15) & ~size_t(15))) + 64;
+    const size_t stride = (std::max(lds_dp, lds_f) + 255) & ~size_t(255);
+    const size_t need = stride * (size_t)u->n_utt;
+    if (need > u->k2_gscratch_bytes) {
+      DEVFREE(u->k2_gscratch_d);
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&u->k2_gscratch_d), need));
+      u->k2_gscratch_bytes = need;
+    }
+    a.gscratch = u->k2_gscratch_d; a.gscratch_stride = (int64_t)stride;
+    KernelTimer kt(ctx, "k2_viterbi_dp");
+    hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false, true>), dim3(u->n_utt), dim3(nthr), 0, ctx->stream, a);
+  } else {
+    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
+                     : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
+    if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
+    if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     KernelTimer kt(ctx, "k2_viterbi_dp");
     if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
@@ -1034,12 +1050,14 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     // the one-lane form handles everything else
     const int odeg = std::max(1, (int)u->max_outdeg);
     const size_t lds_w = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 8 * (S + 1) + 5 * 4 * A + 8 * ((S * odeg + 63) / 64 + 2) + A + 64;
-    const bool wave_ok = !u->has_eps && S <= 1000 && odeg <= 8 && lds_w <= 160 * 1024 && getenv("KHG_K2_SERIAL") == nullptr;
+    const bool wave_ok = !gmem && !u->has_eps && S <= 1000 && odeg <= 8 && lds_w <= 160 * 1024 && getenv("KHG_K2_SERIAL") == nullptr;
     if (wave_ok) {
       if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
       hipLaunchKernelGGL(k2_viterbi_faithful_wave, dim3(u->n_utt), dim3(64), lds_w, side, a, odeg);
+    } else if (gmem) {
+      hipLaunchKernelGGL(k2_viterbi_faithful<true>, dim3(u->n_utt), dim3(64), 0, side, a);
     } else {
-      hipLaunchKernelGGL(k2_viterbi_faithful, dim3(u->n_utt), dim3(64), lds_f, side, a);
+      hipLaunchKernelGGL(k2_viterbi_faithful<false>, dim3(u->n_utt), dim3(64), lds_f, side, a);
     }
   }
   HIPCHK(hipGetLastError());

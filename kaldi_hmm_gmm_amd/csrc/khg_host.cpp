@@ -411,3 +411,35 @@ extern "C" int khg_diag_gmm_merge(int32_t* num_gauss, int32_t D, int32_t target,
   if (!ComputeGconstsOne(kept, D, weights, iv, miv, gconsts, &nb)) return khg_set_error(KHG_E_RUNTIME, "not a number in gconst computation");
   return KHG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// ModifyGraphForCarefulAlignment (csrc/decoder-wrappers.cc:111-140) on flat CSR arrays.
+extern "C" int khg_careful_graph(int32_t S, int32_t start, const int64_t* arc_off, const int32_t* il, const int32_t* ol,
+                                 const float* wt, const int32_t* ns, const float* fin, int32_t* oS, int32_t* ostart,
+                                 int64_t* o_off, int32_t* o_il, int32_t* o_ol, float* o_wt, int32_t* o_ns, float* o_fin) {
+  if (S < 0 || !oS || !ostart || !o_off) return khg_set_error(KHG_E_ARG, "khg_careful_graph: bad arguments");
+  if (S == 0) { *oS = 0; *ostart = start; o_off[0] = 0; return KHG_OK; }     // "Empty FST input." -- left as it is
+  if (!arc_off || !il || !ol || !wt || !ns || !fin || !o_il || !o_ol || !o_wt || !o_ns || !o_fin || start < 0 || start >= S)
+    return khg_set_error(KHG_E_ARG, "khg_careful_graph: bad arguments");
+  const int32_t pre_initial = 2 * S;
+  int64_t n = 0;
+  auto put = [&](int32_t i, int32_t o, float w, int32_t d) { o_il[n] = i; o_ol[n] = o; o_wt[n] = w; o_ns[n] = d; ++n; };
+  for (int32_t s = 0; s < S; ++s) {                       // left copy: own arcs, then the Concat epsilon of a final state
+    o_off[s] = n;
+    for (int64_t a = arc_off[s]; a < arc_off[s + 1]; ++a) put(il[a], ol[a], wt[a], ns[a]);
+    if (!std::isinf(fin[s])) put(0, 0, fin[s], pre_initial);
+    o_fin[s] = INFINITY;
+  }
+  for (int32_t s = 0; s < S; ++s) {                       // right copy, no final weights
+    o_off[S + s] = n;
+    for (int64_t a = arc_off[s]; a < arc_off[s + 1]; ++a) put(il[a], ol[a], wt[a], ns[a] + S);
+    o_fin[S + s] = INFINITY;
+  }
+  o_off[pre_initial] = n;                                 // the pre-initial state of the right copy: final (One) + epsilon to its start
+  put(0, 0, 0.0f, start + S);
+  o_fin[pre_initial] = 0.0f;
+  o_off[pre_initial + 1] = n;
+  *oS = 2 * S + 1;
+  *ostart = start;
+  return KHG_OK;
+}

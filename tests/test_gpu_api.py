@@ -443,3 +443,43 @@ def test_accs_as_torch_aliases_the_device_block_and_all_reduces(ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("beam,retry", [(200.0, 0.0), (6.0, 30.0)])
+def test_graphs_too_large_for_lds_decode_from_hbm_scratch(ctx, beam, retry):
+    """A decoding graph of thousands of states (tables beyond the 160 KB of LDS: khg_align used to refuse it) runs the
+    generic DP and the order-faithful decoder out of an HBM scratch slice; status / alignment / words equal the oracle's
+    FasterDecoder on the same scores.  One graph has epsilon-input arcs with word labels (no beam certificate path)."""
+    from kaldi_hmm_gmm_amd import DeviceModel, DeviceTransitions, UtteranceSet, synth
+
+    rng = np.random.default_rng(77)
+    m = synth.make_model(30, 3, 8, seed=5)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    graphs = [random_graph(rng, m.num_tids, n_main=3000, p_branch=0.3, p_eps=0.0),
+              random_graph(rng, m.num_tids, n_main=2600, p_branch=0.5, p_eps=0.15, p_long=0.3),
+              random_graph(rng, m.num_tids, n_main=40, p_branch=0.3, p_eps=0.0)]
+    T = [3100, 2700, 90]
+    frame_off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+    feats = (rng.standard_normal((int(frame_off[-1]), 8)) * 2.0).astype(np.float32)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    tm.set_trans_cost(np.zeros(m.num_tids + 1, np.float32))
+    us = UtteranceSet(ctx, tm, frame_off, feats, graphs=concat(graphs))
+    us.loglikes(dm)
+    lls = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.3)
+    for u, g in enumerate(graphs):
+        og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+        want = orc.align_utterance_ll(og, m.id2pdf, T[u], pdfs[poff[u]: poff[u + 1]], lls[u], acoustic_scale=0.3, beam=beam, retry_beam=retry)
+        st = int(res["status"][u])
+        assert (st & 3) == (want["status"] & 3), (u, st, want["status"])
+        a = res["ali"][frame_off[u]: frame_off[u + 1]]
+        if want["status"] & 1:
+            assert (a == 0).all()
+        else:
+            assert np.array_equal(a, want["ali"]), u
+            assert np.array_equal(res["words"][res["words_off"][u]: res["words_off"][u + 1]], want["words"]), u
+            assert abs(res["like"][u] - want["like"]) <= 1e-5 * abs(want["like"]) + 1e-3
+    for o in (us, tm, dm):
+        o.close()

@@ -466,3 +466,55 @@ def test_gmm_boost_silence_returns_a_boosted_copy():
             np.testing.assert_allclose(out.get_pdf(p).gconsts, gc0[p] + np.log(1.5), rtol=1e-6, atol=1e-5)
         else:
             assert np.array_equal(out.get_pdf(p).weights, w0[p]) and np.array_equal(out.get_pdf(p).gconsts, gc0[p])
+
+
+def test_careful_graph_c_abi_vs_oracle_and_python_fst():
+    """khg_careful_graph (host C-ABI: csrc/decoder-wrappers.cc:111-140 + OpenFst Concat) == the oracle's restatement ==
+    the package's StdVectorFst form, on random graphs with several final states, and an empty graph."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from graphs import random_graph
+    from kaldi_hmm_gmm_amd.fst import StdArc, StdVectorFst, modify_graph_for_careful_alignment
+    from kaldi_hmm_gmm_amd._lib import lib, ptr, check
+    rng = np.random.default_rng(21)
+    for trial in range(12):
+        g = random_graph(rng, 40, n_main=int(rng.integers(1, 12)), p_branch=0.4, p_eps=0.3)
+        S = len(g["final"]); A = len(g["ilabel"])
+        if trial % 3 == 0 and S > 2:
+            g["final"][S // 2] = np.float32(0.25)              # a second final state
+        start = int(g["start"])
+        o = orc.careful_graph(orc.OGraph(start, g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"]))
+        ao = np.zeros(2 * S + 2, np.int64); il = np.zeros(2 * A + S + 1, np.int32); ol = np.zeros_like(il)
+        w = np.zeros(2 * A + S + 1, np.float32); ns = np.zeros_like(il); fin = np.zeros(2 * S + 1, np.float32)
+        nS, st = C.c_int32(), C.c_int32()
+        a64 = np.ascontiguousarray(g["arc_off"], np.int64)
+        check(lib.khg_careful_graph(S, start, ptr(a64, C.c_int64), ptr(g["ilabel"], C.c_int32), ptr(g["olabel"], C.c_int32),
+                                    ptr(g["weight"], C.c_float), ptr(g["nextstate"], C.c_int32), ptr(g["final"], C.c_float),
+                                    C.byref(nS), C.byref(st), ptr(ao, C.c_int64), ptr(il, C.c_int32), ptr(ol, C.c_int32),
+                                    ptr(w, C.c_float), ptr(ns, C.c_int32), ptr(fin, C.c_float)))
+        n = int(ao[nS.value])
+        assert nS.value == 2 * S + 1 == o.final.shape[0] and st.value == start == o.c.start
+        assert n == 2 * A + 1 + int(np.isfinite(g["final"]).sum()) == o.ilabel.shape[0]
+        assert np.array_equal(ao[: nS.value + 1], o.arc_off) and np.array_equal(fin, o.final)
+        for got, want in ((il[:n], o.ilabel), (ol[:n], o.olabel), (w[:n], o.weight), (ns[:n], o.nextstate)):
+            assert np.array_equal(got, want)
+        # the package's graph class (what AlignConfig.careful uses above the C-ABI)
+        f = StdVectorFst()
+        for _ in range(S):
+            f.add_state()
+        f.start = start
+        for s in range(S):
+            for a in range(int(g["arc_off"][s]), int(g["arc_off"][s + 1])):
+                f.add_arc(s, StdArc(int(g["ilabel"][a]), int(g["olabel"][a]), float(g["weight"][a]), int(g["nextstate"][a])))
+            if np.isfinite(g["final"][s]):
+                f.set_final(s, float(g["final"][s]))
+        modify_graph_for_careful_alignment(f)
+        assert f.num_states == nS.value
+        flat = [(a.ilabel, a.olabel, np.float32(a.weight), a.nextstate) for s in range(f.num_states) for a in f._arcs[s]]
+        assert flat == list(zip(il[:n].tolist(), ol[:n].tolist(), w[:n], ns[:n].tolist()))
+    nS, st = C.c_int32(7), C.c_int32(7)
+    ao = np.ones(2, np.int64)
+    check(lib.khg_careful_graph(0, -1, None, None, None, None, None, None, C.byref(nS), C.byref(st), ptr(ao, C.c_int64), None, None,
+                                None, None, None))
+    assert nS.value == 0 and st.value == -1 and ao[0] == 0
