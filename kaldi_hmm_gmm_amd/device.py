@@ -445,3 +445,29 @@ class DeviceAccs:
             self.close()
         except Exception:
             pass
+
+
+# ---- the pybind11 host surface (csrc/khg_pybind.cpp) ----------------------------------------------------------------------
+# The classes above are the ctypes twin of the C++ classes of `_kaldi_hmm_gmm_amd`, the module that corresponds to the
+# reference's `_kaldi_hmm_gmm` (python/csrc/kaldi-hmm-gmm.cc:35-69).  When the extension is built (it is by
+# `__graft_entry__.build()`), the package uses the C++ classes; KHG_BINDING=ctypes keeps the twins (same API, same C-ABI
+# underneath -- either way every call ends in libkhg_hip.so, there is no other implementation).
+import os as _os
+
+BINDING = "ctypes"
+if _os.environ.get("KHG_BINDING", "pybind11") != "ctypes":
+    try:
+        from . import _kaldi_hmm_gmm_amd as _ext
+    except ImportError:
+        _ext = None
+    if _ext is not None:
+        _ext._set_error_class(_lib.KhgError)
+        _CtypesDeviceAccs = DeviceAccs
+        Context, Comm, DeviceModel, DeviceTransitions, UtteranceSet = (_ext.Context, _ext.Comm, _ext.DeviceModel, _ext.DeviceTransitions,
+                                                                   _ext.UtteranceSet)
+
+        class DeviceAccs(_ext.DeviceAccs):
+            """AccumAmDiagGmm + transition stats as one fp64 device buffer (C++ class; as_torch is the only Python part)."""
+            as_torch = _CtypesDeviceAccs.as_torch
+
+        BINDING = "pybind11"

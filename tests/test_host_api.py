@@ -518,3 +518,45 @@ def test_careful_graph_c_abi_vs_oracle_and_python_fst():
     check(lib.khg_careful_graph(0, -1, None, None, None, None, None, None, C.byref(nS), C.byref(st), ptr(ao, C.c_int64), None, None,
                                 None, None, None))
     assert nS.value == 0 and st.value == -1 and ao[0] == 0
+
+
+def test_pybind11_module_is_the_host_surface():
+    """The pybind11 module `_kaldi_hmm_gmm_amd` (csrc/khg_pybind.cpp; the reference's boundary is `_kaldi_hmm_gmm`,
+    python/csrc/kaldi-hmm-gmm.cc:35-69) is built, is what kaldi_hmm_gmm_amd's device classes are, raises KhgError like
+    the reference's RuntimeError, and its host functions agree with the ctypes route to the same C-ABI."""
+    from kaldi_hmm_gmm_amd import device
+    ext = pytest.importorskip("kaldi_hmm_gmm_amd._kaldi_hmm_gmm_amd")
+    if os.environ.get("KHG_BINDING") != "ctypes":
+        assert device.BINDING == "pybind11"
+        assert khg.Context is ext.Context and khg.UtteranceSet is ext.UtteranceSet and khg.DeviceModel is ext.DeviceModel
+        assert issubclass(khg.DeviceAccs, ext.DeviceAccs) and khg.Comm is ext.Comm
+    for cls, methods in ((ext.Context, "sync set_timing timings set_k1_form close"),
+                         (ext.DeviceModel, "set_weights mle_update scale_weights download close"),
+                         (ext.DeviceTransitions, "set_trans_cost close"),
+                         (ext.UtteranceSet, "set_pdf_list pdf_lists pdf_first_frames loglikes loglikes_layout download_loglikes "
+                                            "upload_loglikes align upload_ali download_ali acc_stats close"),
+                         (ext.DeviceAccs, "zero device_ptr allreduce split relayout download_range download_occ download_trans download "
+                                          "upload close"),
+                         (ext.Comm, "unique_id close")):
+        for name in methods.split():
+            assert hasattr(cls, name), (cls, name)
+    assert ext.version() == 100 and issubclass(khg.KhgError, RuntimeError)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(khg.KhgError, match="no HIP device"):
+            ext.Context(0)
+    rng = np.random.default_rng(4)
+    am = _rand_am(rng, 3, 4, 5)
+    go, gc, w, miv, iv = am.flat()
+    gc2, bad = ext.compute_gconsts(go, w, iv, miv)
+    assert bad == 0 and np.array_equal(gc2, gc)
+    g = am.get_pdf(1)
+    r = ext.diag_gmm_merge(g.weights, g.means_invvars, g.inv_vars, 2)
+    o = orc.diag_gmm_merge(g.weights, g.means_invvars, g.inv_vars, 2)
+    assert r["num_gauss"] == 2 and r["history"] == o["history"]
+    for k in ("weights", "gconsts", "means_invvars", "inv_vars"):
+        np.testing.assert_array_equal(r[k][:2], o[k])
+    topo, tree, tm = _tm()
+    c = ext.scaled_trans_cost(np.asarray(tm.log_probs, np.float32), np.asarray(tm.non_self_loop_log_probs, np.float32),
+                              np.asarray(tm.id2state, np.int32), np.asarray([0] + [int(tm.is_self_loop(t)) for t in range(1, tm.num_transition_ids + 1)], np.uint8), 1.0, 0.1)
+    np.testing.assert_array_equal(c, tm.scaled_trans_cost(1.0, 0.1))

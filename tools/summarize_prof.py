@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r1"
-OURS = ("k1_loglikes", "k1p_", "k2_viterbi", "k3_", "k4_", "k0_pack", "rocprim")
+OURS = ("k1_loglikes", "k1p_", "k1b_", "k0b_", "k2_viterbi", "k3_", "k4_", "k0_pack", "c1_", "rocprim", "rccl", "nccl")
 
 
 def short(name):
@@ -75,7 +75,14 @@ if bench_line:
 fetch = counters("pmc_fetch")
 write = counters("pmc_write")
 mfma = counters("pmc_mfma")
-summary = {"command": "tools/profile_r1.sh", "kernels": {}}
+import hashlib
+_h = hashlib.sha256()
+_d = os.path.join(ROOT, "kaldi_hmm_gmm_amd", "csrc")
+for _fn in sorted(os.listdir(_d)):            # same identity bench.py computes (csrc_sha): which kernels the profile belongs to
+    if _fn.endswith((".hip", ".inc", ".cpp", ".h")):
+        with open(os.path.join(_d, _fn), "rb") as _fh:
+            _h.update(_fn.encode() + b"\0" + _fh.read())
+summary = {"command": f"tools/profile_{TAG}.sh", "csrc_sha": _h.hexdigest()[:16], "kernels": {}}
 if bench_line:
     nb = bench_line["roofline"]["launches_per_step"]
     summary["utterances_per_launch"] = bench_line["config"]["utterances"] / nb
@@ -97,7 +104,9 @@ for k in sorted(set(fetch) | set(write) | set(mfma)):
         gui = mean(mfma[k].get("GRBM_GUI_ACTIVE", []))
         e["SQ_VALU_MFMA_BUSY_CYCLES"] = busy
         e["GRBM_GUI_ACTIVE"] = gui
-        e["SQ_INSTS_VALU_MFMA_MOPS_F32"] = mean(mfma[k].get("SQ_INSTS_VALU_MFMA_MOPS_F32", []))
+        for cn in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+            if cn in mfma[k]:
+                e[cn] = mean(mfma[k][cn])
         # busy cycles are summed over the 1024 SIMDs, GUI_ACTIVE over the 8 XCDs
         e["mfma_busy_frac"] = (busy / 1024.0) / (gui / 8.0) if gui else None
     for r in stats:
@@ -109,7 +118,7 @@ with open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 
 lines = [f"# Round {TAG[1:]} rocprofv3 summaries (MI355X, gfx950)", "",
-         "Produced by `tools/profile_r1.sh` on the GPU box and `tools/summarize_prof.py` here: one",
+         f"Produced by `tools/profile_{TAG}.sh` on the GPU box and `tools/summarize_prof.py` here: one",
          "`rocprofv3 --kernel-trace --stats` run of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
          "(the default workload: 100 000 utterances, one launch of each kernel per step), then three separate",
          "`--pmc` runs of the same command (FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE).", "",
@@ -126,11 +135,11 @@ for k, e in summary["kernels"].items():
                  f"{e.get('traffic_bytes', 0) / 1e9:.2f} | {'' if mb is None else f'{mb:.3f}'} |")
 if bench_line:
     rf = bench_line["roofline"]
-    lines += ["", f"Bench line under the profiler ({TAG}_bench_under_rocprof.json): K1 {rf['kernel_ms']:.2f} ms per launch by HIP events, "
-              f"{rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of the 157.3 TFLOP/s fp32 MFMA peak."]
+    lines += ["", f"Bench line under the profiler ({TAG}_bench_under_rocprof.json): K1 ({rf['kernel']}) {rf['kernel_ms']:.2f} ms per launch by HIP events, "
+              f"{rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of the {rf['peak']:g} TFLOP/s MFMA peak of its arithmetic."]
 notes = os.path.join(DST, f"{TAG}_notes.md")
 if os.path.exists(notes):
     lines += ["", open(notes).read().rstrip()]
-with open(os.path.join(DST, "README.md"), "w") as fh:
+with open(os.path.join(DST, "README.md" if TAG == "r1" else f"{TAG}_README.md"), "w") as fh:
     fh.write("\n".join(lines) + "\n")
 print("\n".join(lines))
