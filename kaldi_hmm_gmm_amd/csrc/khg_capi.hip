@@ -363,6 +363,7 @@ struct khg_utts {
   std::vector<int32_t> pdf_first;  // per (utterance, listed pdf): first frame at which any state emitting it can hold a token
   int tiles_reach = -1;            // whether the walk lists carry those first frames (reachable-only K1) or zeros
   std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
+  int64_t* tile2_off_d = nullptr; int32_t* tiles2_d = nullptr; std::vector<int32_t> tiles2_pto; int tiles2_reach = -1;   // bf16x3: pair walk
   float* ll_d = nullptr; int64_t ll_total = 0; bool ll_valid = false;
   // K1, pdf-major form: repacked features (once), work plan (per reachable flag)
   float* xpl_d = nullptr; int64_t* utt_xtile_off_d = nullptr; int32_t xpl_kq = 0;
@@ -563,6 +564,7 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   plan_ll(u);
   DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d);
   DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear(); u->tiles_reach = -1;
+  DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d); u->tiles2_pto.clear(); u->tiles2_reach = -1;
   DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d); u->p_reach = -1;
   u->ll_valid = false;
   return KHG_OK;
@@ -576,7 +578,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
-  DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d);
+  DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
@@ -806,7 +808,7 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool r
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
   a.dbg = getenv("KHG_K1B_DBG") ? atoi(getenv("KHG_K1B_DBG")) : 0;
   if (u->n_bchunks > 0) {
-    const size_t lds = (size_t)k1b_ring(KS) * k1b_tile_bytes(KS);
+    const size_t lds = (size_t)k1b_ring(KS) * k1b_group(KS) * k1b_tile_bytes(KS);
     const void* fn = KS == 5 ? (const void*)k1b_loglikes<5, 2> : (const void*)k1b_loglikes<10, 1>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(ctx, "k1_loglikes");
