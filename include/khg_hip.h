@@ -271,6 +271,13 @@ int khg_model_set_weights(khg_ctx *ctx, khg_model *m, const float *weights_h);
 int khg_model_mle_update(khg_ctx *ctx, khg_model *m, const khg_accs *a, const khg_mle_options *o,
                          uint16_t flags, float *objf_change, float *count, int32_t *floored_elems,
                          int32_t *floored_gauss, int32_t *removed);
+/* Mixing up on the handle: AmDiagGmm::SplitByCount's per-pdf DiagGmm::Split (csrc/am-diag-gmm.cc:72-90, csrc/diag-gmm.cc:780-851)
+ * to targets_h[p] >= current components (the caller computes them with GetSplitTargets, csrc/model-common.cc:29-70, from
+ * the per-pdf occupancies -- khg_accs_download_range(0, sumG)).  The reference draws the perturbations from the process-global
+ * rand(); here they are INJECTED: randn_h holds (sum of new components) x dim standard normal deviates, consumed pdf by pdf
+ * in split order, so every rank of a multi-GPU job (and the host form) perturbs identically.  Parameters bit-identical to
+ * the host form, gconsts through logf.  The handle is updated in place (call khg_accs_relayout afterwards). */
+int khg_model_split(khg_ctx *ctx, khg_model *m, const int32_t *targets_h, float perturb_factor, const float *randn_h);
 /* total Gaussians and (gauss_off_h may be NULL) the current gauss_off[num_pdfs+1] of the handle */
 int khg_model_num_gauss(const khg_model *m, int64_t *total, int32_t *gauss_off_h);
 /* parameters back to the host (AmDiagGmm::Write needs them); any pointer may be NULL */

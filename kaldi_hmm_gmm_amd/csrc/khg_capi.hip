@@ -1528,6 +1528,57 @@ extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* 
   return KHG_OK;
 }
 
+extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* targets, float perturb, const float* randn) {
+  if (!ctx || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_split: bad arguments");
+  if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_split: the model has no weights (khg_model_set_weights)");
+  const int P = m->P, D = m->D;
+  std::vector<int32_t> new_off((size_t)P + 1, 0);
+  std::vector<int64_t> rand_off((size_t)P + 1, 0);
+  for (int p = 0; p < P; ++p) {
+    const int cur = m->gauss_off[p + 1] - m->gauss_off[p];
+    if (targets[p] < cur)   // csrc/diag-gmm.cc:782-786
+      return khg_set_error(KHG_E_RUNTIME, "Cannot split from " + std::to_string(cur) + " to " + std::to_string(targets[p]) + " components");
+    new_off[(size_t)p + 1] = new_off[(size_t)p] + targets[p];
+    rand_off[(size_t)p + 1] = rand_off[(size_t)p] + (targets[p] - cur);
+  }
+  const int64_t nnew = rand_off[(size_t)P], out = new_off[(size_t)P];
+  if (nnew == 0) return KHG_OK;
+  if (!randn) return khg_set_error(KHG_E_ARG, "khg_model_split: randn_h is NULL");
+  std::vector<float> rv(randn, randn + (size_t)nnew * D);
+  int32_t *new_off_d = nullptr, *bad_d = nullptr;
+  int64_t* rand_off_d = nullptr;
+  float *rand_d = nullptr, *w2 = nullptr, *gc2 = nullptr, *miv2 = nullptr, *iv2 = nullptr;
+  int rc = dev_upload(ctx, &new_off_d, new_off);
+  if (!rc) rc = dev_upload(ctx, &rand_off_d, rand_off);
+  if (!rc) rc = dev_upload(ctx, &rand_d, rv);
+  if (!rc) rc = dev_alloc(&bad_d, 1);
+  if (!rc) rc = dev_alloc(&w2, (size_t)out);
+  if (!rc) rc = dev_alloc(&gc2, (size_t)out);
+  if (!rc) rc = dev_alloc(&miv2, (size_t)out * D);
+  if (!rc) rc = dev_alloc(&iv2, (size_t)out * D);
+  int32_t bad = 0;
+  if (!rc) {
+    hipError_t e = hipMemsetAsync(bad_d, 0, sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess) {
+      KernelTimer kt(ctx, "k4_split");
+      hipLaunchKernelGGL(k4_split, dim3(P), dim3(256), 0, ctx->stream, m->gauss_off_d, new_off_d, D, m->weights_d, m->miv_d, m->iv_d, w2, gc2,
+                         miv2, iv2, rand_d, rand_off_d, perturb, bad_d);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, bad_d, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  }
+  DEVFREE(new_off_d); DEVFREE(rand_off_d); DEVFREE(rand_d); DEVFREE(bad_d);
+  if (!rc && bad) rc = khg_set_error(KHG_E_RUNTIME, "khg_model_split: not a number in gconst computation");
+  if (rc) { DEVFREE(w2); DEVFREE(gc2); DEVFREE(miv2); DEVFREE(iv2); return rc; }
+  DEVFREE(m->weights_d); DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d);
+  m->weights_d = w2; m->gconsts_d = gc2; m->miv_d = miv2; m->iv_d = iv2;
+  m->gauss_off = new_off;
+  m->sumG = out;
+  return model_pack(ctx, m);
+}
+
 // After khg_model_mle_update removed Gaussians the accumulator block is laid out for fewer rows.
 extern "C" int khg_accs_relayout(khg_ctx* ctx, khg_accs* a, const khg_model* m) {
   if (!ctx || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_relayout: bad arguments");

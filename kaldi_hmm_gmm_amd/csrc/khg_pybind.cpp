@@ -125,6 +125,16 @@ struct KModel {
   }
   py::dict mle_update(KAccs& accs, py::object opts, int flags);
   void scale_weights(Arr<int32_t> pdfs, float scale) { Check(khg_model_scale_weights(ctx->h, h, (int32_t)pdfs.shape(0), pdfs.data(), scale)); }
+  void split(Arr<int32_t> targets, float perturb, py::object randn) {
+    if (targets.shape(0) != num_pdfs) throw py::value_error("split: one target per pdf");
+    Arr<float> r;
+    const float* rp = nullptr;
+    if (!randn.is_none()) { r = randn.cast<Arr<float>>(); rp = r.data(); }
+    Check(khg_model_split(ctx->h, h, targets.data(), perturb, rp));
+    Arr<int32_t> go({(py::ssize_t)num_pdfs + 1});
+    Check(khg_model_num_gauss(h, nullptr, go.mutable_data()));
+    gauss_off = go;
+  }
   py::dict download(bool weights) {
     const py::ssize_t G = sumG();
     Arr<float> gc({G}), miv({G, (py::ssize_t)dim}), iv({G, (py::ssize_t)dim});
@@ -424,6 +434,7 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def("set_weights", &KModel::set_weights)
       .def("mle_update", &KModel::mle_update, py::arg("accs"), py::arg("opts") = py::none(), py::arg("flags") = 0x7)
       .def("scale_weights", &KModel::scale_weights)
+      .def("split", &KModel::split, py::arg("targets"), py::arg("perturb_factor"), py::arg("randn"))
       .def("download", &KModel::download, py::arg("weights") = true)
       .def("close", &KModel::close);
 

@@ -140,6 +140,16 @@ class DeviceModel:
         return {"objf_change": oc.value, "count": cnt.value, "floored_elements": fe.value, "floored_gaussians": fg.value,
                 "removed": rm.value}
 
+    def split(self, targets, perturb_factor: float, randn):
+        """Mixing up on the handle (khg_model_split = DiagGmm::Split per pdf, csrc/diag-gmm.cc:780-851): targets[p] components
+        per pdf; randn: float32 [sum of new components, dim] injected normal deviates, consumed in (pdf, split) order."""
+        t = _lib.as_np(targets, np.int32)
+        r = _lib.as_np(randn, np.float32) if randn is not None else None
+        check(lib.khg_model_split(self.ctx.h, self.h, ptr(t, C.c_int32), float(perturb_factor), ptr(r, C.c_float)))
+        go = np.zeros(self.num_pdfs + 1, np.int32)
+        check(lib.khg_model_num_gauss(self.h, None, ptr(go, C.c_int32)))
+        self.gauss_off = go
+
     def scale_weights(self, pdfs, scale: float):
         """gmm_boost_silence (scripts/gmm_boost_silence.py:10-45) on the handle: weights of `pdfs` *= scale,
         their gconsts recomputed."""

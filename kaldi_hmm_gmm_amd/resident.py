@@ -10,9 +10,10 @@ metric is quoted on ("model, graphs and features resident in HBM")
     accumulate()  K3 into the fp64 block, then ONE all-reduce of the block when torch.distributed is
                   initialised (utterances are sharded over ranks, csrc/mle-am-diag-gmm.cc:119-128 == gmm-sum-accs)
     update()      transition update on the host (a few kB come down), GMM update on the device (K4,
-                  khg_model_mle_update); every rank holds the same all-reduced sums, so every rank computes the
-                  same new model and nothing is broadcast.  Only a pass that mixes up goes through the host
-                  (DiagGmm::Split draws random numbers; scripts/gmm_est.py:66-84).
+                  khg_model_mle_update), mixing up on the device too (khg_model_split: the per-pdf occupancies come
+                  down, the normal deviates DiagGmm::Split needs go up; scripts/gmm_est.py:66-84); every rank holds the
+                  same all-reduced sums and draws the same deviates, so every rank computes the same new model and
+                  nothing is broadcast.
 
 Utterances whose alignment fails contribute no statistics until they align again."""
 from typing import Dict, List, Optional, Sequence
@@ -182,13 +183,17 @@ class ResidentEm:
         info.update(gmm_objf_impr=r["objf_change"], gmm_count=r["count"], frames=float(tot_t),
                     avg_like=float(tot_like / tot_t) if tot_t else float("nan"), removed=r["removed"])
         if mixup != 0:
+            # AmDiagGmm::SplitByCount (csrc/am-diag-gmm.cc:72-90) on the device model (khg_model_split): nothing comes down
+            # but the occupancies; the normal deviates are drawn here in the order DiagGmm::Split would consume them
             targets = get_split_targets(pdf_occs, mixup, power, min_count)
             cur = np.diff(self.dm.gauss_off)
-            if any(t > c for t, c in zip(targets, cur)):
-                am = self.sync_host()
-                am.split_by_count(state_occs=pdf_occs, target_components=mixup, perturb_factor=perturb_factor, power=power,
-                                  min_count=min_count, randn=randn)
-                self._upload_model()
+            tgt = np.maximum(np.asarray(targets, np.int64), cur).astype(np.int32)
+            n_new = int((tgt - cur).sum())
+            if n_new > 0:
+                D = self.dm.dim
+                normals = np.concatenate([np.asarray(randn(D), np.float32).reshape(D) for _ in range(n_new)]).reshape(n_new, D)
+                self.dm.split(tgt, perturb_factor, normals)
+                self.accs.relayout(self.dm)
         return info
 
     def close(self):

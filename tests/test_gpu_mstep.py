@@ -236,3 +236,48 @@ def test_device_m_step_variance_floor_vector(ctx):
         for name in ("weights", "inv_vars", "means_invvars"):
             np.testing.assert_array_equal(d[name][a:b], ref[name], err_msg=f"pdf {p} {name} vs oracle")
     assert _ulps(d["gconsts"], h_gc).max() <= GC_ULPS
+
+
+def test_device_split_equals_host_split(ctx):
+    """khg_model_split (DiagGmm::Split per pdf on the device, injected normal deviates) == the host form (DiagGmm.split,
+    csrc/diag-gmm.cc:780-851 restated) fed the same deviates: gauss_off, weights, inv_vars, means_invvars bit for bit,
+    gconsts within the logf tolerance; a pdf whose target equals its size is left alone; a smaller target is an error."""
+    import kaldi_hmm_gmm_amd as khg
+
+    P, Gmax, D = 11, 6, 13
+    rng = np.random.default_rng(5)
+    m = synth.make_model(P, Gmax, D, seed=12, ragged=True)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    cur = np.diff(m.gauss_off)
+    tgt = (cur + rng.integers(0, 5, P)).astype(np.int32)
+    tgt[3] = cur[3]
+    n_new = int((tgt - cur).sum())
+    normals = rng.standard_normal((n_new, D)).astype(np.float32)
+    # host form, pdf by pdf, consuming the same stream
+    it = iter(normals)
+    want_w, want_miv, want_iv, want_gc = [], [], [], []
+    for p in range(P):
+        a, b = int(m.gauss_off[p]), int(m.gauss_off[p + 1])
+        g = khg.DiagGmm(nmix=b - a, dim=D)
+        g.set_weights(m.weights[a:b]); g.set_invvars(m.inv_vars[a:b]); g._means_invvars = m.means_invvars[a:b].copy(); g.compute_gconsts()
+        g.split(int(tgt[p]), 0.01, randn=lambda d: next(it))
+        want_w.append(g.weights); want_miv.append(g.means_invvars); want_iv.append(g.inv_vars); want_gc.append(g.gconsts)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    dm.split(tgt, 0.01, normals)
+    d = dm.download()
+    assert np.array_equal(d["gauss_off"], np.concatenate([[0], np.cumsum(tgt)]).astype(np.int32))
+    np.testing.assert_array_equal(d["weights"], np.concatenate(want_w))
+    np.testing.assert_array_equal(d["inv_vars"], np.concatenate(want_iv))
+    np.testing.assert_array_equal(d["means_invvars"], np.concatenate(want_miv))
+    assert _ulps(d["gconsts"], np.concatenate(want_gc)).max() <= GC_ULPS
+    # the split model scores: K1 on the new tile image gives finite log-likes
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    us = UtteranceSet(ctx, None, np.array([0, 40], np.int64), rng.standard_normal((40, D)).astype(np.float32))
+    us.set_pdf_list(np.arange(P, dtype=np.int32))
+    us.loglikes(dm)
+    assert np.isfinite(us.download_loglikes()[0]).all()
+    from kaldi_hmm_gmm_amd import KhgError
+    with pytest.raises(KhgError, match="Cannot split"):
+        dm.split(np.maximum(tgt - 1, 1).astype(np.int32), 0.01, normals)
+    for o in (us, tm, dm):
+        o.close()
