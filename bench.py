@@ -40,10 +40,10 @@ def parse():
     ap.add_argument("--batches", type=int, default=1, help="utterance batches per rank (more batches bound the score/back-pointer buffers and let a batch's serial fallback decoder overlap the next batch's K1)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
-    ap.add_argument("--k1", choices=["auto", "bf16x3", "pdf", "utt"], default="auto",
-                    help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = bf16x3 (bf16 matrix cores at fp32 accuracy); pdf / utt = "
-                         "the fp32-MFMA forms")
-    ap.add_argument("--no-fp32-line", action="store_true", help="skip the two extra steps that time the fp32-MFMA K1 beside a bf16x3 run")
+    ap.add_argument("--k1", choices=["auto", "f16x2", "bf16x3", "pdf", "utt"], default="auto",
+                    help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = f16x2 (fp16 matrix cores at fp32 accuracy, 3 partial "
+                         "products); bf16x3 = bf16 matrix cores, 6 partial products; pdf / utt = the fp32-MFMA forms")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the two extra steps that time the fp32-MFMA K1 beside an f16x2 / bf16x3 run")
     ap.add_argument("--seed", type=int, default=20230418)
     ap.add_argument("--allreduce", choices=["khg", "torch", "khg-f32", "host"], default="khg",
                     help="C1: khg = khg_accs_allreduce (RCCL called by the library on the kernels' stream); torch = "
@@ -259,7 +259,8 @@ def main():
     torch.cuda.set_stream(streams[0])
     ctxs = [Context(local, stream=st.cuda_stream) for st in streams]
     env_k1 = os.environ.get("KHG_K1")
-    k1_form = {"fp32": "pdf"}.get(env_k1, env_k1) if env_k1 in ("bf16x3", "pdf", "utt", "fp32") else ("bf16x3" if args.k1 == "auto" else args.k1)
+    k1_form = {"fp32": "pdf"}.get(env_k1, env_k1) if env_k1 in ("f16x2", "bf16x3", "pdf", "utt", "fp32") else ("f16x2" if args.k1 == "auto" else args.k1)
+    split_form = k1_form in ("f16x2", "bf16x3")      # fp32 operands split into 16-bit pieces for the 16-bit matrix cores
     for c in ctxs:
         c.set_k1_form(k1_form)
     dm = DeviceModel(ctxs[0], model.gauss_off, gc, model.means_invvars, model.inv_vars)
@@ -296,7 +297,7 @@ def main():
             poff_, _ = s_.pdf_lists()
             first = s_.pdf_first_frames().astype(np.int64)
             Tu = np.repeat(np.diff(s_.frame_off), np.diff(poff_))
-            if k1_form == "bf16x3":                 # whole 32-frame tiles (first needed 16-frame tile, clamped to 127, halved)
+            if split_form:                          # whole 32-frame tiles (first needed 16-frame tile, clamped to 127, halved)
                 skipped_cells += float(np.minimum(32 * (np.minimum(first // 16, 127) // 2), Tu).sum())
             else:
                 skipped_cells += float(np.minimum(16 * (first // 16), Tu).sum())
@@ -372,7 +373,7 @@ def main():
 
     # the fp32-MFMA K1 beside a bf16x3 run: the same step, K1 switched to the pdf-major fp32 kernel (1 warm-up + 2 timed steps)
     fp32_line = None
-    if k1_form == "bf16x3" and not args.no_fp32_line:
+    if split_form and not args.no_fp32_line:
         for c in ctxs:
             c.set_k1_form("pdf")
         step()
@@ -452,11 +453,14 @@ def main():
         traffic, traffic_src = pmc_traffic(frames_local / nb)
         cells = k1_flops_per_launch / (4.0 * D * G + 5.0 * G)          # (frame, pdf) cells per launch, dense contract
         t_k1 = k1_avg_ms * 1e-3
-        if k1_form == "bf16x3":
-            # every fp32 multiply-add of the contraction is six bf16 multiply-adds (khg_k1_bf16x3.hip.inc): the bf16 FLOPs of the
-            # SURVEY 8(d) contract are cells x (6 x 4DG + 5G), priced against the dense bf16 MFMA peak
-            bflops = cells * (24.0 * D * G + 5.0 * G)
-            roofline = {"bound": "mfma", "kernel": "k1_loglikes (k1b_loglikes: v_mfma_f32_32x32x16_bf16, bf16x3)", "achieved": bflops / t_k1 / 1e12,
+        if split_form:
+            # every fp32 multiply-add of the contraction is NPROD 16-bit multiply-adds (3: khg_k1_f16x2.hip.inc, 6:
+            # khg_k1_bf16x3.hip.inc): the 16-bit FLOPs of the SURVEY 8(d) contract are cells x (NPROD x 4DG + 5G), priced against
+            # the dense fp16 / bf16 MFMA peak (the same 2.5 PFLOP/s)
+            nprod = 3 if k1_form == "f16x2" else 6
+            bflops = cells * (nprod * 4.0 * D * G + 5.0 * G)
+            kname = ("k1h_loglikes: v_mfma_f32_32x32x16_f16, f16x2" if k1_form == "f16x2" else "k1b_loglikes: v_mfma_f32_32x32x16_bf16, bf16x3")
+            roofline = {"bound": "mfma", "kernel": "k1_loglikes (%s)" % kname, "achieved": bflops / t_k1 / 1e12,
                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bflops / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                         "frac_executed": bflops * k1_exec_frac / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                         "fp32_equivalent": {"achieved": k1_flops_per_launch / t_k1 / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -465,10 +469,11 @@ def main():
                                                     "peak the fp32 kernels are bound by: > 1 means past that roofline"},
                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                         "executed_cell_fraction": k1_exec_frac,
-                        "note": "achieved/frac: bf16 FLOPs of the dense T x P_u contract (6 bf16 partial products per fp32 product) / kernel time "
-                                "/ the 2.5 PFLOP/s dense bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame tiles "
-                                "(executed_cell_fraction); frac_executed = frac x that fraction.  Under a bare bf16 MFMA loop this chip holds "
-                                "1.8 GHz = 1.8 PFLOP/s (tools/mfma_bf16_chain.hip), 0.72 of the spec peak",
+                        "note": "achieved/frac: 16-bit FLOPs of the dense T x P_u contract (%d partial products per fp32 product) / kernel time "
+                                "/ the 2.5 PFLOP/s dense fp16 = bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame "
+                                "tiles (executed_cell_fraction); frac_executed = frac x that fraction.  Under a bare 16-bit MFMA loop this chip "
+                                "holds 1.8 GHz = 1.8 PFLOP/s (tools/mfma_bf16_chain.hip), 0.72 of the spec peak.  With 3 products the log-sum-exp "
+                                "(VALU, ~90 instructions per 15 MFMAs) shares the issue port with the MFMAs about evenly" % nprod,
                         "kernel_ms": k1_avg_ms, "flops_per_launch": bflops, "launches_per_step": nb}
         else:
             ach = k1_flops_per_launch / t_k1 / 1e12
@@ -491,12 +496,18 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if k1_form != "bf16x3" else "f32 via bf16x3",
-            "dtype_note": None if k1_form != "bf16x3" else
-            "log-likelihood contraction: fp32 operands split EXACTLY into three bf16 pieces, the six partial products of weight >= 2^-16 on "
-            "the bf16 matrix cores, fp32 accumulate -- measured error vs fp64 BELOW the fp32 fmaf chain's (max 4.4e-7 B vs 6.0e-7 B, "
-            "gpurun_out/probe_bf16x3.txt), every fp64-bound tolerance test unchanged; everything else fp32 / fp64 as the reference; the "
-            "fp32-MFMA K1 is timed beside it in fp32_mfma_line (--k1 pdf runs it as the whole bench)",
+            "dtype": "f32" if not split_form else "f32 via " + k1_form,
+            "dtype_note": None if not split_form else (
+                "log-likelihood contraction: fp32 operands rescaled per k by an exact power of two and written as v1 + v2 2^-11 with two fp16 "
+                "pieces (|v - (v1 + v2 2^-11)| <= 2^-24 |v|), the three partial products w1 x1, w1 x2, w2 x1 on the fp16 matrix cores with "
+                "fp32 accumulators -- worst case 3 x 2^-24 per term, measured error vs fp64 BELOW the fp32 fmaf chain's (max 3.0e-7 B vs "
+                "7.4e-7 B, profiles/r2_probe_f16x2.txt), every fp64-bound tolerance test unchanged; models whose operands do not fit fp16 "
+                "under any scaling run the bf16x3 form; everything else fp32 / fp64 as the reference; the fp32-MFMA K1 is timed beside it "
+                "in fp32_mfma_line (--k1 pdf runs it as the whole bench)" if k1_form == "f16x2" else
+                "log-likelihood contraction: fp32 operands split EXACTLY into three bf16 pieces, the six partial products of weight >= 2^-16 on "
+                "the bf16 matrix cores, fp32 accumulate -- measured error vs fp64 BELOW the fp32 fmaf chain's (max 4.4e-7 B vs 6.0e-7 B, "
+                "profiles/r2_probe_bf16x3.txt), every fp64-bound tolerance test unchanged; everything else fp32 / fp64 as the reference; the "
+                "fp32-MFMA K1 is timed beside it in fp32_mfma_line (--k1 pdf runs it as the whole bench)"),
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} pdfs x {G} Gauss, dim {D}, {args.utts} utterances "
                                    f"({frames_total} frames) sharded over {world} GPU(s), beam {args.beam:g}, "

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkhg_hip.so")
+LIB_PATH = os.environ.get("KHG_LIBRARY") or os.path.join(_HERE, "libkhg_hip.so")   # KHG_LIBRARY: A/B builds (ctypes binding only)
 
 
 class KhgError(RuntimeError):

@@ -22,6 +22,7 @@
 #include "khg_k1_loglikes.hip.inc"
 #include "khg_k1_pdfmajor.hip.inc"
 #include "khg_k1_bf16x3.hip.inc"
+#include "khg_k1_f16x2.hip.inc"
 #include "khg_k2_viterbi.hip.inc"
 #include "khg_k3_accstats.hip.inc"
 #include "khg_k4_mstep.hip.inc"
@@ -139,7 +140,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
   return KHG_OK;
 }
 extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) {
-  if (!c || form < KHG_K1_AUTO || form > KHG_K1_FP32_UTT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_k1_form: bad arguments");
+  if (!c || form < KHG_K1_AUTO || form > KHG_K1_F16X2) return khg_set_error(KHG_E_ARG, "khg_ctx_set_k1_form: bad arguments");
   c->k1_form = form;
   return KHG_OK;
 }
@@ -212,6 +213,13 @@ struct khg_model {
   int32_t wimg_tiles = 0;       // tiles wimg_d was allocated for
   char* wimgb_d = nullptr;      // bf16x3 K1 image (khg_k1_bf16x3.hip.inc), k1b_tile_bytes(KS) per 32-Gaussian tile
   int32_t wimgb_tiles = 0, KS = 0;
+  // f16x2 K1 image (khg_k1_f16x2.hip.inc): packed lazily by khg_loglikes with the scale exponents of the utterance set
+  char* wimgh_d = nullptr;
+  int32_t wimgh_tiles = 0;
+  std::vector<int32_t> wimgh_ex;   // exponents the image was packed with (empty: stale)
+  std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
+  float gcmax = 0.0f;              // max |gconst| over the finite ones (valid with wmax)
+  int32_t* tile_pdf_d = nullptr;   // tile -> pdf map of the current layout
 };
 
 // (Re)build everything derived from gauss_off + the row-major parameters in HBM: the tile offsets, the K1
@@ -246,21 +254,23 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
   std::vector<int32_t> tile_pdf((size_t)nt);   // tile -> pdf map for the pack kernel
   for (int p = 0; p < P; ++p)
     for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
-  int32_t* tile_pdf_d = nullptr;
-  int rc = dev_upload(ctx, &tile_pdf_d, tile_pdf);
+  DEVFREE(m->tile_pdf_d);
+  m->wimgh_ex.clear();
+  m->wmax.clear();
+  int rc = dev_upload(ctx, &m->tile_pdf_d, tile_pdf);
+  int32_t* tile_pdf_d = m->tile_pdf_d;
   if (!rc) {
     KernelTimer kt(ctx, "k0_pack_tiles");
     if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
     else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
-    if (m->KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d);
-    else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d);
+    if (m->KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d, ctx->err_flag_d);
+    else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d, ctx->err_flag_d);
   }
   if (!rc) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // tile_pdf and the host offset vectors are free after this
     if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
   }
-  DEVFREE(tile_pdf_d);
   return rc;
 }
 
@@ -294,7 +304,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 }
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
@@ -373,6 +383,10 @@ struct khg_utts {
   // K1, bf16x3 form: B fragments of the features (once), workgroup chunks
   k1b_u32x4* xb3_d = nullptr; int64_t* utt_x32_off_d = nullptr; int32_t xb3_ks = 0;
   K1bChunk* bchunks_d = nullptr; int32_t n_bchunks = 0, bchunk_nt = 0;
+  int32_t* x32_utt_d = nullptr; int64_t n_x32 = 0;        // 32-frame tile -> utterance
+  // K1, f16x2 form: B fragments packed with the scale exponents xh_ex (per k = 2 d + kind)
+  k1b_u32x4* xh_d = nullptr; int32_t xh_ks = 0; std::vector<int32_t> xh_ex; int32_t* xh_ex_d = nullptr;
+  std::vector<float> xmax;         // per feature dimension: max |x| over the set (empty: not computed)
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
@@ -578,7 +592,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
-  DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
+  DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d); DEVFREE(u->xh_d); DEVFREE(u->xh_ex_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
@@ -760,45 +774,57 @@ static int ensure_walk(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reach
   return KHG_OK;
 }
 
+// 32-frame tile layout of the set shared by the bf16x3 and f16x2 forms: tile offsets per utterance, tile -> utterance,
+// workgroup chunks of <= 8 NTMAX tiles.
+static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
+  if (u->utt_x32_off_d && u->bchunk_nt == NTMAX) return KHG_OK;
+  DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d);
+  DEVFREE(u->xb3_d); DEVFREE(u->xh_d);
+  u->xb3_ks = 0; u->xh_ks = 0;
+  std::vector<int64_t> xoff((size_t)u->n_utt + 1, 0);
+  for (int i = 0; i < u->n_utt; ++i) xoff[(size_t)i + 1] = xoff[(size_t)i] + (u->frame_off[i + 1] - u->frame_off[i] + 31) / 32;
+  const int64_t nx = xoff[(size_t)u->n_utt];
+  std::vector<int32_t> xutt((size_t)nx);
+  std::vector<K1bChunk> ch;
+  const int per = 8 * NTMAX;
+  for (int i = 0; i < u->n_utt; ++i) {
+    const int n32 = (int)(xoff[(size_t)i + 1] - xoff[(size_t)i]);
+    for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
+    if (u->pdf_off[i + 1] == u->pdf_off[i]) continue;
+    // chunks of equal size (a 17-tile utterance becomes 9 + 8 tiles, not 16 + 1)
+    const int nch = (n32 + per - 1) / per;
+    for (int c = 0; c < nch; ++c) {
+      const int t0 = (int)((int64_t)n32 * c / nch), t1 = (int)((int64_t)n32 * (c + 1) / nch);
+      if (t1 > t0) ch.push_back(K1bChunk{i, t0, t1 - t0, 0});
+    }
+  }
+  int rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
+  if (!rc) rc = dev_upload(ctx, &u->x32_utt_d, xutt);
+  if (!rc) rc = dev_upload(ctx, &u->bchunks_d, ch);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  u->n_x32 = nx; u->n_bchunks = (int32_t)ch.size(); u->bchunk_nt = NTMAX;
+  return KHG_OK;
+}
+
 // K1 on the bf16 matrix cores (khg_k1_bf16x3.hip.inc): B fragments of the features (once per set), chunks, walk.
 static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
-  int rc = KHG_OK;
   const int KS = m->KS, NTMAX = KS == 5 ? 2 : 1;
+  int rc = ensure_x32(ctx, u, NTMAX);
+  if (rc) return rc;
   if (!u->xb3_d || u->xb3_ks != KS) {
-    DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d);
-    std::vector<int64_t> xoff((size_t)u->n_utt + 1, 0);
-    for (int i = 0; i < u->n_utt; ++i) xoff[(size_t)i + 1] = xoff[(size_t)i] + (u->frame_off[i + 1] - u->frame_off[i] + 31) / 32;
-    const int64_t nx = xoff[(size_t)u->n_utt];
-    std::vector<int32_t> xutt((size_t)nx);
-    std::vector<K1bChunk> ch;
-    const int per = 8 * NTMAX;
-    for (int i = 0; i < u->n_utt; ++i) {
-      const int n32 = (int)(xoff[(size_t)i + 1] - xoff[(size_t)i]);
-      for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
-      if (u->pdf_off[i + 1] == u->pdf_off[i]) continue;
-      // chunks of equal size (a 17-tile utterance becomes 9 + 8 tiles, not 16 + 1)
-      const int nch = (n32 + per - 1) / per;
-      for (int c = 0; c < nch; ++c) {
-        const int t0 = (int)((int64_t)n32 * c / nch), t1 = (int)((int64_t)n32 * (c + 1) / nch);
-        if (t1 > t0) ch.push_back(K1bChunk{i, t0, t1 - t0, 0});
-      }
-    }
-    int32_t* xutt_d = nullptr;
-    rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
-    if (!rc) rc = dev_upload(ctx, &xutt_d, xutt);
-    if (!rc) rc = dev_upload(ctx, &u->bchunks_d, ch);
-    if (!rc) rc = dev_alloc(&u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
+    DEVFREE(u->xb3_d);
+    const int64_t nx = u->n_x32;
+    rc = dev_alloc(&u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
     if (!rc && nx > 0) {
       const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
-      if (KS == 5) hipLaunchKernelGGL(k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, xutt_d, nx, u->D, u->xb3_d);
-      else hipLaunchKernelGGL(k1b_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, xutt_d, nx, u->D, u->xb3_d);
+      if (KS == 5) hipLaunchKernelGGL(k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
+      else hipLaunchKernelGGL(k1b_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
       hipError_t e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
     }
-    DEVFREE(xutt_d);
     if (rc) return rc;
-    u->xb3_ks = KS; u->n_bchunks = (int32_t)ch.size(); u->bchunk_nt = NTMAX;
+    u->xb3_ks = KS;
   }
   rc = ensure_walk(ctx, m, u, reachable_only);
   if (rc) return rc;
@@ -816,6 +842,173 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool r
     else hipLaunchKernelGGL((k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
     HIPCHK(hipGetLastError());
   }
+  u->ll_valid = true;
+  return KHG_OK;
+}
+
+// column maxima of |a[n][D]| -> host
+static int absmax_cols(khg_ctx* ctx, const float* a_d, int64_t n, int D, std::vector<float>* out) {
+  uint32_t* m_d = nullptr;
+  int rc = dev_alloc(&m_d, 128);
+  if (rc) return rc;
+  std::vector<uint32_t> h(128, 0);
+  hipError_t e = hipMemsetAsync(m_d, 0, 128 * sizeof(uint32_t), ctx->stream);
+  if (e == hipSuccess && n > 0) {
+    const int gb = (int)std::min<int64_t>(4096, (n + 1) / 2);
+    hipLaunchKernelGGL(k1h_absmax, dim3(gb), dim3(256), 0, ctx->stream, a_d, n, D, m_d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), m_d, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  DEVFREE(m_d);
+  if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  out->resize((size_t)D);
+  for (int d = 0; d < D; ++d) memcpy(&(*out)[(size_t)d], &h[(size_t)d], sizeof(float));
+  return KHG_OK;
+}
+
+// f16x2 scale exponents (khg_k1_f16x2.hip.inc): per k = 2 d + kind, x' = x 2^e and w' = w 2^-e.  `fits`: every scaled
+// operand stays <= 2^15 (fp16 overflows at 65504).
+static const float K1H_LIMIT = 32768.0f;
+static bool k1h_fits(const std::vector<int32_t>& ex, const std::vector<float>& xk, const std::vector<float>& wk) {
+  for (size_t k = 0; k < ex.size(); ++k) {
+    if (!(std::ldexp(xk[k], ex[k]) <= K1H_LIMIT) || !(std::ldexp(wk[k], -ex[k]) <= K1H_LIMIT)) return false;
+  }
+  return true;
+}
+static void k1h_balance(const std::vector<float>& xk, const std::vector<float>& wk, std::vector<int32_t>* ex) {
+  ex->assign(xk.size(), 0);
+  for (size_t k = 0; k < xk.size(); ++k) {
+    const bool hx = xk[k] > 0.0f && std::isfinite(xk[k]), hw = wk[k] > 0.0f && std::isfinite(wk[k]);
+    double e = 0.0;
+    if (hx && hw) e = 0.5 * (std::log2((double)wk[k]) - std::log2((double)xk[k]));
+    else if (hx) e = -std::log2((double)xk[k]);      // only one side has values: bring its maximum to ~1
+    else if (hw) e = std::log2((double)wk[k]);
+    (*ex)[k] = (int32_t)std::lrint(std::min(120.0, std::max(-120.0, e)));
+  }
+}
+
+// Exact maxima behind the split forms' domain check and the f16x2 scales: per feature dimension over the set (once), per
+// k = 2 d + kind and over the gconsts for the model (once per parameter version).  -> xk[k] = max |X[k][.]|.
+static int k1_maxima(khg_ctx* ctx, khg_model* m, khg_utts* u, std::vector<float>* xk) {
+  const int D = m->D, K = 16 * m->KS;
+  int rc = KHG_OK;
+  if (u->xmax.empty()) { rc = absmax_cols(ctx, u->feats_d, u->N, D, &u->xmax); if (rc) return rc; }
+  if (m->wmax.empty()) {
+    std::vector<float> a, b, g;
+    rc = absmax_cols(ctx, m->miv_d, m->sumG, D, &a);
+    if (!rc) rc = absmax_cols(ctx, m->iv_d, m->sumG, D, &b);
+    if (!rc) rc = absmax_cols(ctx, m->gconsts_d, m->sumG, 1, &g);
+    if (rc) return rc;
+    m->wmax.assign((size_t)K, 0.0f);
+    for (int d = 0; d < D; ++d) { m->wmax[(size_t)2 * d] = a[(size_t)d]; m->wmax[(size_t)2 * d + 1] = 0.5f * b[(size_t)d]; }
+    m->gcmax = g[0];
+  }
+  xk->assign((size_t)K, 0.0f);
+  for (int d = 0; d < D; ++d) { (*xk)[(size_t)2 * d] = u->xmax[(size_t)d]; (*xk)[(size_t)2 * d + 1] = u->xmax[(size_t)d] * u->xmax[(size_t)d]; }
+  return KHG_OK;
+}
+// The split forms (f16x2, bf16x3) fold the log-sum-exp's subtraction into an fma (k1_exp2_le1): valid while every
+// log-likelihood term sum stays below 2^28 in magnitude (khg_k1_f16x2.hip.inc, "Domain").
+static bool k1_split_domain(const khg_model* m, const std::vector<float>& xk) {
+  double bound = (double)m->gcmax;
+  for (size_t k = 0; k < xk.size(); ++k) bound += (double)m->wmax[k] * (double)xk[k];
+  return bound <= 268435456.0;      // also false for NaN / inf
+}
+
+// K1 on the fp16 matrix cores (khg_k1_f16x2.hip.inc).  -> KHG_OK, an error, or +1: outside the split forms' domain (the
+// caller runs an fp32-MFMA form).
+static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachable_only) {
+  const int KS = m->KS, NTMAX = KS == 5 ? 2 : 1, D = m->D, K = 16 * KS;
+  std::vector<float> xk;
+  int rc = k1_maxima(ctx, m, u, &xk);
+  if (rc) return rc;
+  if (!k1_split_domain(m, xk)) return 1;
+  rc = ensure_x32(ctx, u, NTMAX);
+  if (rc) return rc;
+  // the set's planes are kept while the model still fits their scales
+  const bool have_x = u->xh_d && u->xh_ks == KS && (int)u->xh_ex.size() == K;
+  if (!have_x || !k1h_fits(u->xh_ex, xk, m->wmax)) {
+    std::vector<int32_t> ex;
+    k1h_balance(xk, m->wmax, &ex);
+    if (!k1h_fits(ex, xk, m->wmax)) return 1;
+    const int64_t nx = u->n_x32;
+    if (!u->xh_d || u->xh_ks != KS) {
+      DEVFREE(u->xh_d);
+      rc = dev_alloc(&u->xh_d, (size_t)std::max<int64_t>(nx, 1) * 2 * KS * 64);
+      if (rc) return rc;
+    }
+    DEVFREE(u->xh_ex_d);
+    rc = dev_upload(ctx, &u->xh_ex_d, ex);
+    if (rc) return rc;
+    if (nx > 0) {
+      KernelTimer kt(ctx, "k1h_pack_x");
+      const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
+      if (KS == 5) hipLaunchKernelGGL(k1h_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
+      else hipLaunchKernelGGL(k1h_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));    // `ex` (pageable) is free after this
+    u->xh_ks = KS; u->xh_ex = ex;
+  }
+  if (m->wimgh_ex != u->xh_ex) {
+    if (!m->wimgh_d || m->wimgh_tiles < m->ntiles) {
+      DEVFREE(m->wimgh_d);
+      rc = dev_alloc(&m->wimgh_d, (size_t)m->ntiles * k1h_tile_bytes(KS));
+      if (rc) return rc;
+      m->wimgh_tiles = m->ntiles;
+    }
+    KernelTimer kt(ctx, "k0h_pack_tiles");
+    if (KS == 5) hipLaunchKernelGGL(k0h_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
+    else hipLaunchKernelGGL(k0h_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
+    HIPCHK(hipGetLastError());
+    m->wimgh_ex = u->xh_ex;
+  }
+  rc = ensure_walk(ctx, m, u, reachable_only);
+  if (rc) return rc;
+  K1hArgs a;
+  a.xh = u->xh_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->bchunks_d;
+  a.wimg = m->wimgh_d; a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
+  a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
+  a.dbg = getenv("KHG_K1B_DBG") ? atoi(getenv("KHG_K1B_DBG")) : 0;
+  a.tbuf = nullptr;
+#ifdef K1H_TIMING
+  uint64_t* tbuf_d = nullptr;
+  if (u->n_bchunks > 0) {
+    rc = dev_alloc(&tbuf_d, (size_t)u->n_bchunks * 64);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(tbuf_d, 0, (size_t)u->n_bchunks * 64 * sizeof(uint64_t), ctx->stream));
+    a.tbuf = tbuf_d;
+  }
+#endif
+  if (u->n_bchunks > 0) {
+    const size_t lds = (size_t)k1h_lds_bytes(KS);
+    const void* fn = KS == 5 ? (const void*)k1h_loglikes<5, 2> : (const void*)k1h_loglikes<10, 1>;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer kt(ctx, "k1_loglikes");
+    if (KS == 5) hipLaunchKernelGGL((k1h_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k1h_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+  }
+#ifdef K1H_TIMING
+  if (tbuf_d) {      // measurement build only: per-wave cycle breakdown, averaged by the number of frame tiles the wave owns
+    std::vector<uint64_t> h((size_t)u->n_bchunks * 64);
+    HIPCHK(hipMemcpyAsync(h.data(), tbuf_d, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double sum[3][8] = {};
+    long cnt[3] = {0, 0, 0};
+    for (size_t w = 0; w < h.size() / 8; ++w) {
+      const uint64_t* o = &h[w * 8];
+      if (o[5] == 0 || o[6] > 2) continue;
+      for (int i = 0; i < 8; ++i) sum[o[6]][i] += (double)o[i];
+      ++cnt[o[6]];
+    }
+    for (int nt = 0; nt < 3; ++nt)
+      if (cnt[nt]) fprintf(stderr, "k1h timing NT=%d waves=%ld: per wave cycles(100MHz-or-core clock units): barrier %.0f frag-wait %.0f chains %.0f tail %.0f total %.0f; tiles %.1f intervals %.1f\n",
+                           nt, cnt[nt], sum[nt][0] / cnt[nt], sum[nt][1] / cnt[nt], sum[nt][2] / cnt[nt], sum[nt][3] / cnt[nt], sum[nt][5] / cnt[nt], sum[nt][4] / cnt[nt], sum[nt][7] / cnt[nt]);
+    DEVFREE(tbuf_d);
+  }
+#endif
   u->ll_valid = true;
   return KHG_OK;
 }
@@ -841,12 +1034,24 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     int form = ctx->k1_form;
     if (const char* env = getenv("KHG_K1")) {
       if (strcmp(env, "bf16x3") == 0) form = KHG_K1_BF16X3;
+      else if (strcmp(env, "f16x2") == 0) form = KHG_K1_F16X2;
       else if (strcmp(env, "pdf") == 0 || strcmp(env, "fp32") == 0) form = KHG_K1_FP32_PDF;
       else if (strcmp(env, "utt") == 0) form = KHG_K1_FP32_UTT;
     }
-    if (form == KHG_K1_AUTO) form = KHG_K1_BF16X3;
+    if (form == KHG_K1_AUTO) form = KHG_K1_F16X2;
     if (u->N == 0 || u->pdfs.empty()) { u->ll_valid = true; return KHG_OK; }
-    if (form == KHG_K1_BF16X3) return loglikes_bf16x3(ctx, m, u, reachable_only);
+    if (form == KHG_K1_F16X2) {
+      rc = loglikes_f16x2(ctx, const_cast<khg_model*>(m), u, reachable_only);
+      if (rc <= 0) return rc;
+      form = KHG_K1_FP32_PDF;        // magnitudes outside the split forms' domain
+    }
+    if (form == KHG_K1_BF16X3) {
+      std::vector<float> xk;
+      rc = k1_maxima(ctx, const_cast<khg_model*>(m), u, &xk);
+      if (rc) return rc;
+      if (k1_split_domain(m, xk)) return loglikes_bf16x3(ctx, m, u, reachable_only);
+      form = KHG_K1_FP32_PDF;
+    }
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     if (form == KHG_K1_FP32_PDF && maxG <= 128) return loglikes_pdf_major(ctx, m, u, reachable_only);

