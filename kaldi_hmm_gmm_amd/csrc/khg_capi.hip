@@ -1471,16 +1471,25 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       a.ll_part = u->k3_llpart_d;
       a.part = ny > 1 ? u->k3_part_d : nullptr;
       KernelTimer kt(ctx, "k3_accumulate");
+      // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
+      // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
+      const char* pb = getenv("KHG_K3_PHASEB");
+      const bool exact_b = !(pb && strcmp(pb, "f32") == 0);
+      // k3_accumulate_wave32: the workgroup's fp64 image + W + two x planes per wave
+      const size_t lds32 = sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16) + sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 2 * 16 * 20);
+#define K3_WAVE_LAUNCH(NBV)                                                                                            \
+  do {                                                                                                                  \
+    if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);          \
+    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(m->P, ny), dim3(256), lds32, ctx->stream, a);              \
+    if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny);               \
+  } while (0)
       switch (nb) {
-        case 1: hipLaunchKernelGGL((k3_accumulate_wave<1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<1>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
-        case 2: hipLaunchKernelGGL((k3_accumulate_wave<2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<2>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
-        case 3: hipLaunchKernelGGL((k3_accumulate_wave<3>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<3>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
-        default: hipLaunchKernelGGL((k3_accumulate_wave<4>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-                if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<4>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny); break;
+        case 1: K3_WAVE_LAUNCH(1); break;
+        case 2: K3_WAVE_LAUNCH(2); break;
+        case 3: K3_WAVE_LAUNCH(3); break;
+        default: K3_WAVE_LAUNCH(4); break;
       }
+#undef K3_WAVE_LAUNCH
       hipLaunchKernelGGL(k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
     } else if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block

@@ -368,6 +368,41 @@ def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, monkey
     np.testing.assert_allclose(got["occ"], occ64, rtol=2e-4, atol=1e-6)
 
 
+def test_acc_stats_fp32_phase_b_option(ctx, monkeypatch):
+    """KHG_K3_PHASEB=f32 (k3_accumulate_wave32: gamma . x on the fp32 matrix pipe, 256-frame fp32 partial sums widened into a
+    per-workgroup fp64 image): within the statistics' tolerance of the default (products exact in fp64), transition counts
+    and frame totals identical, and run-to-run reproducible bit for bit."""
+    from kaldi_hmm_gmm_amd import DeviceAccs
+
+    m, gc, om, ut, cost = build(20, 64, 40, n_utt=120, seed=33, max_phones=8)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.upload_ali(ut.ref_ali)
+
+    def run():
+        accs = DeviceAccs(ctx, dm, tm)
+        us.acc_stats(dm, tm, accs, weight=0.5)
+        st = accs.download()
+        accs.close()
+        return st
+
+    exact = run()
+    monkeypatch.setenv("KHG_K3_PHASEB", "f32")
+    a, b = run(), run()
+    for k in ("occ", "mean_acc", "var_acc", "trans_acc"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["trans_acc"], exact["trans_acc"]) and a["total_frames"] == exact["total_frames"]
+    assert a["total_log_like"] == exact["total_log_like"]           # phase A and the softmax are the same code
+    np.testing.assert_allclose(a["occ"], exact["occ"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(a["mean_acc"], exact["mean_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["mean_acc"]).max())
+    np.testing.assert_allclose(a["var_acc"], exact["var_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["var_acc"]).max())
+    assert not np.array_equal(a["mean_acc"], exact["mean_acc"])      # it really is the other kernel
+    for ny in ("3",):                                                # several blocks per pdf: parked slices, same tolerance
+        monkeypatch.setenv("KHG_K3_NY", ny)
+        c = run()
+        np.testing.assert_allclose(c["mean_acc"], exact["mean_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["mean_acc"]).max())
+        np.testing.assert_allclose(c["occ"], exact["occ"], rtol=2e-5, atol=1e-6)
+
+
 def test_acc_stats_reproducible_bit_for_bit(ctx, monkeypatch):
     """Wave-form K3 (the default for <= 64 Gaussians, D <= 40): stable bucket sort, per-pdf tile order, waves and pdf
     slices folded in a fixed order, one atomic per cell -- repeated passes give identical bits, with one block per pdf
