@@ -86,7 +86,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(frames_per_launch):
+def pmc_traffic(frames_per_launch, k1_form="f16x2"):
     """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction) -- bench.py cannot run the profiler on
     itself.  Only reported when the profile was taken at this launch size AND on these kernel sources (csrc_sha);
@@ -96,7 +96,8 @@ def pmc_traffic(frames_per_launch):
         try:
             with open(path) as fh:
                 pm = json.load(fh)
-            k1 = next(v for k, v in pm["kernels"].items() if k.startswith(("k1p_loglikes", "k1_loglikes", "k1b_loglikes")))
+            want = {"f16x2": "k1h_loglikes", "bf16x3": "k1b_loglikes", "pdf": "k1p_loglikes", "utt": "k1_loglikes"}[k1_form]
+            k1 = next(v for k, v in pm["kernels"].items() if k.startswith(want))
             rel = os.path.relpath(path, ROOT)
             if abs(pm["frames_per_launch"] / frames_per_launch - 1.0) > 0.02:
                 return None, f"{rel}: collected at another launch size ({pm['frames_per_launch']} frames)"
@@ -450,7 +451,7 @@ def main():
                   "gaussians_after": int(r_up[0][-1]),
                   "note": "not part of value (SURVEY 8d: M-step reported separately); host = threaded C++ update between an "
                           "accumulator download and a parameter upload; device = K4 on the accumulators where K3 left them"}
-        traffic, traffic_src = pmc_traffic(frames_local / nb)
+        traffic, traffic_src = pmc_traffic(frames_local / nb, k1_form)
         cells = k1_flops_per_launch / (4.0 * D * G + 5.0 * G)          # (frame, pdf) cells per launch, dense contract
         t_k1 = k1_avg_ms * 1e-3
         if split_form:

@@ -213,6 +213,7 @@ struct khg_model {
   int32_t wimg_tiles = 0;       // tiles wimg_d was allocated for
   char* wimgb_d = nullptr;      // bf16x3 K1 image (khg_k1_bf16x3.hip.inc), k1b_tile_bytes(KS) per 32-Gaussian tile
   int32_t wimgb_tiles = 0, KS = 0;
+  bool wimgb_valid = false;       // packed from the current parameters (lazily: only the bf16x3 form reads it)
   // f16x2 K1 image (khg_k1_f16x2.hip.inc): packed lazily by khg_loglikes with the scale exponents of the utterance set
   char* wimgh_d = nullptr;
   int32_t wimgh_tiles = 0;
@@ -245,12 +246,7 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     m->wimg_tiles = nt;
   }
   m->KS = m->KQ == 10 ? 5 : 10;
-  if (!m->wimgb_d || m->wimgb_tiles < nt) {
-    DEVFREE(m->wimgb_d);
-    int rc = dev_alloc(&m->wimgb_d, (size_t)nt * k1b_tile_bytes(m->KS));
-    if (rc) return rc;
-    m->wimgb_tiles = nt;
-  }
+  m->wimgb_valid = false;
   std::vector<int32_t> tile_pdf((size_t)nt);   // tile -> pdf map for the pack kernel
   for (int p = 0; p < P; ++p)
     for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
@@ -263,8 +259,6 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     KernelTimer kt(ctx, "k0_pack_tiles");
     if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
     else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
-    if (m->KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d, ctx->err_flag_d);
-    else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimgb_d, ctx->err_flag_d);
   }
   if (!rc) {
     hipError_t e = hipGetLastError();
@@ -808,10 +802,24 @@ static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
 }
 
 // K1 on the bf16 matrix cores (khg_k1_bf16x3.hip.inc): B fragments of the features (once per set), chunks, walk.
-static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
+static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool reachable_only) {
+  khg_model* m = const_cast<khg_model*>(mc);
   const int KS = m->KS, NTMAX = KS == 5 ? 2 : 1;
   int rc = ensure_x32(ctx, u, NTMAX);
   if (rc) return rc;
+  if (!m->wimgb_valid) {          // the bf16x3 image of the current parameters
+    if (!m->wimgb_d || m->wimgb_tiles < m->ntiles) {
+      DEVFREE(m->wimgb_d);
+      rc = dev_alloc(&m->wimgb_d, (size_t)m->ntiles * k1b_tile_bytes(KS));
+      if (rc) return rc;
+      m->wimgb_tiles = m->ntiles;
+    }
+    KernelTimer kt(ctx, "k0b_pack_tiles");
+    if (KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
+    else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
+    HIPCHK(hipGetLastError());
+    m->wimgb_valid = true;
+  }
   if (!u->xb3_d || u->xb3_ks != KS) {
     DEVFREE(u->xb3_d);
     const int64_t nx = u->n_x32;
@@ -918,8 +926,11 @@ static bool k1_split_domain(const khg_model* m, const std::vector<float>& xk) {
 
 // K1 on the fp16 matrix cores (khg_k1_f16x2.hip.inc).  -> KHG_OK, an error, or +1: outside the split forms' domain (the
 // caller runs an fp32-MFMA form).
+#ifndef K1H_NT10
+#define K1H_NT10 2      // 32-frame tiles per wave at D <= 80 (12 spilled registers; 1: none)
+#endif
 static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachable_only) {
-  const int KS = m->KS, NTMAX = KS == 5 ? 2 : 1, D = m->D, K = 16 * KS;
+  const int KS = m->KS, NTMAX = KS == 5 ? 2 : K1H_NT10, D = m->D, K = 16 * KS;
   std::vector<float> xk;
   int rc = k1_maxima(ctx, m, u, &xk);
   if (rc) return rc;
@@ -983,11 +994,11 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
 #endif
   if (u->n_bchunks > 0) {
     const size_t lds = (size_t)k1h_lds_bytes(KS);
-    const void* fn = KS == 5 ? (const void*)k1h_loglikes<5, 2> : (const void*)k1h_loglikes<10, 1>;
+    const void* fn = KS == 5 ? (const void*)k1h_loglikes<5, 2> : (const void*)k1h_loglikes<10, K1H_NT10>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(ctx, "k1_loglikes");
     if (KS == 5) hipLaunchKernelGGL((k1h_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k1h_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k1h_loglikes<10, K1H_NT10>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
     HIPCHK(hipGetLastError());
   }
 #ifdef K1H_TIMING

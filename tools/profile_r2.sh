@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes for profiles/ (round 2): kernel trace + stats, then PMC passes in their own runs (the pool refuses --pmc
-# combined with other trace domains).  The bench runs its default workload (bf16x3 K1) with the fp32-MFMA side line.
+# combined with other trace domains).  The bench runs its default workload (f16x2 K1) with the fp32-MFMA side line.
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r2
@@ -9,6 +9,6 @@ ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS > /dev/null 2> $OUT/pmc_mfma.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS > /dev/null 2> $OUT/pmc_mfma.log
 ls -R $OUT | head -40
 tail -2 $OUT/bench_trace.json | cut -c1-400

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r1"
-OURS = ("k1_loglikes", "k1p_", "k1b_", "k0b_", "k2_viterbi", "k3_", "k4_", "k0_pack", "c1_", "rocprim", "rccl", "nccl")
+OURS = ("k1_loglikes", "k1p_", "k1b_", "k1h_", "k0b_", "k0h_", "k2_viterbi", "k3_", "k4_", "k0_pack", "c1_", "rocprim", "rccl", "nccl")
 
 
 def short(name):
@@ -104,7 +104,7 @@ for k in sorted(set(fetch) | set(write) | set(mfma)):
         gui = mean(mfma[k].get("GRBM_GUI_ACTIVE", []))
         e["SQ_VALU_MFMA_BUSY_CYCLES"] = busy
         e["GRBM_GUI_ACTIVE"] = gui
-        for cn in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+        for cn in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
             if cn in mfma[k]:
                 e[cn] = mean(mfma[k][cn])
         # busy cycles are summed over the 1024 SIMDs, GUI_ACTIVE over the 8 XCDs
