@@ -53,12 +53,17 @@ int khg_ctx_get_timings(khg_ctx *ctx, char *names, int64_t names_cap, float *ms,
 /* Which arithmetic K1 (khg_loglikes*) runs in.  All forms evaluate decodable-am-diag-gmm.cc:55-61 to fp32 accuracy
  * (|error| <= 1e-5 + 1e-6 B against an fp64 evaluation, B = |gconst| + sum |M x| + sum |V x^2| / 2; the reference's own
  * Eigen gemv fixes no summation order either):
- *   KHG_K1_BF16X3    (what AUTO selects) both operands split exactly into three bf16 pieces, the six partial products of
- *                    weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: measured error BELOW the fp32
- *                    chain's (gpurun_out/probe_bf16x3.txt), 16x the matrix rate for 6x the steps;
+ *   KHG_K1_F16X2     (what AUTO selects) both operands rescaled per contraction index by an exact power of two and written
+ *                    as v1 + v2 2^-11 with two fp16 pieces (the representation error is 2^-24 |v|, fp32's own rounding); the
+ *                    three partial products w1 x1, w1 x2, w2 x1 on v_mfma_f32_32x32x16_f16 with fp32 accumulators: measured
+ *                    error BELOW the fp32 chain's (profiles/r2_probe_f16x2.txt).  Used while max |gconst| + sum_k max |w_k|
+ *                    max |x_k| <= 2^28 (exact maxima of the model and the utterance set; ~1e3 for ordinary models); beyond
+ *                    that khg_loglikes runs KHG_K1_FP32_PDF / _UTT by itself;
+ *   KHG_K1_BF16X3    both operands split exactly into three bf16 pieces, the six partial products of weight >= 2^-16 on
+ *                    v_mfma_f32_32x32x16_bf16 with fp32 accumulation (profiles/r2_probe_bf16x3.txt); same domain rule;
  *   KHG_K1_FP32_PDF / KHG_K1_FP32_UTT   fp32 MFMA (v_mfma_f32_16x16x4_f32), pdf-major / utterance-major tiling: bit for bit the
  *                    per-Gaussian chain s = gconst; s = fmaf(M[d], x[d], s) ...; s = fmaf(-V[d]/2, x[d]^2, s) ... in k order.
- * The environment variable KHG_K1 = bf16x3 | pdf | utt overrides the setting (A/B runs). */
+ * The environment variable KHG_K1 = f16x2 | bf16x3 | pdf | utt overrides the setting (A/B runs). */
 #define KHG_K1_AUTO 0
 #define KHG_K1_BF16X3 1
 #define KHG_K1_FP32_PDF 2
