@@ -385,6 +385,7 @@ struct khg_utts {
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
   unsigned char* k2_gscratch_d = nullptr; size_t k2_gscratch_bytes = 0;   // K2 tables of graphs too large for LDS
+  int32_t* k2_order_d = nullptr;   // utterances by length, longest first: the DP kernel's launch order
   int32_t *ali_d = nullptr, *words_d = nullptr, *num_words_d = nullptr, *status_d = nullptr;
   float* like_d = nullptr;
   bool ali_valid = false;
@@ -588,7 +589,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
   DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d); DEVFREE(u->xh_d); DEVFREE(u->xh_ex_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
-  DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d);
+  DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d); DEVFREE(u->k2_order_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
   DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d);
@@ -792,6 +793,12 @@ static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
       if (t1 > t0) ch.push_back(K1bChunk{i, t0, t1 - t0, 0});
     }
   }
+  // longest chunks first: the workgroups still running when the grid drains are then the short ones (a launch of 12 500
+  // utterances -- the 8-GPU shard -- is ~49 rounds of workgroups whose durations differ 4x)
+  // (duration ~ frame tiles x pdfs of the utterance)
+  std::stable_sort(ch.begin(), ch.end(), [&](const K1bChunk& a, const K1bChunk& b) {
+    return (int64_t)a.ntiles * (u->pdf_off[a.utt + 1] - u->pdf_off[a.utt]) > (int64_t)b.ntiles * (u->pdf_off[b.utt + 1] - u->pdf_off[b.utt]);
+  });
   int rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
   if (!rc) rc = dev_upload(ctx, &u->x32_utt_d, xutt);
   if (!rc) rc = dev_upload(ctx, &u->bchunks_d, ch);
@@ -1199,6 +1206,18 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   a.ali = u->ali_d; a.words = u->words_d; a.words_off = u->words_off_d; a.num_words = u->num_words_d;
   a.like = u->like_d; a.status = u->status_d; a.err_flag = ctx->err_flag_d;
   a.prof = nullptr;
+  // launch order of the DP kernel: longest utterances first (built once per set)
+  if (!u->k2_order_d && u->n_utt > 0) {
+    std::vector<int32_t> ord((size_t)u->n_utt);
+    for (int i = 0; i < u->n_utt; ++i) ord[(size_t)i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+      return u->frame_off[x + 1] - u->frame_off[x] > u->frame_off[y + 1] - u->frame_off[y];
+    });
+    int rc2 = dev_upload(ctx, &u->k2_order_d, ord);
+    if (rc2) return rc2;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  a.order = getenv("KHG_K2_INORDER") ? nullptr : u->k2_order_d;
   const bool k2prof = getenv("KHG_K2_PROF") != nullptr;
   if (k2prof) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&a.prof), sizeof(long long) * 8 * (size_t)u->n_utt)); HIPCHK(hipMemset(a.prof, 0, sizeof(long long) * 8 * (size_t)u->n_utt)); }
   a.beam = cfg->beam; a.retry_beam = cfg->retry_beam; a.acoustic_scale = cfg->acoustic_scale;
