@@ -796,9 +796,12 @@ static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
   // longest chunks first: the workgroups still running when the grid drains are then the short ones (a launch of 12 500
   // utterances -- the 8-GPU shard -- is ~49 rounds of workgroups whose durations differ 4x)
   // (duration ~ frame tiles x pdfs of the utterance)
-  std::stable_sort(ch.begin(), ch.end(), [&](const K1bChunk& a, const K1bChunk& b) {
-    return (int64_t)a.ntiles * (u->pdf_off[a.utt + 1] - u->pdf_off[a.utt]) > (int64_t)b.ntiles * (u->pdf_off[b.utt + 1] - u->pdf_off[b.utt]);
-  });
+  {
+    const char* oe = getenv("KHG_K1_ORDER");     // experiments: none | asc | tiles (default: frame tiles x pdfs, descending)
+    auto cost = [&](const K1bChunk& c) { return (int64_t)c.ntiles * ((oe && strcmp(oe, "tiles") == 0) ? 1 : (u->pdf_off[c.utt + 1] - u->pdf_off[c.utt])); };
+    if (oe && strcmp(oe, "asc") == 0) std::stable_sort(ch.begin(), ch.end(), [&](const K1bChunk& a, const K1bChunk& b) { return cost(a) < cost(b); });
+    else if (!(oe && strcmp(oe, "none") == 0)) std::stable_sort(ch.begin(), ch.end(), [&](const K1bChunk& a, const K1bChunk& b) { return cost(a) > cost(b); });
+  }
   int rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
   if (!rc) rc = dev_upload(ctx, &u->x32_utt_d, xutt);
   if (!rc) rc = dev_upload(ctx, &u->bchunks_d, ch);
