@@ -21,6 +21,14 @@ def _libm_expf(x: float) -> float:
     return _libm.expf(x)
 
 
+def _f32_sum(v) -> np.float32:
+    """Sequential float sum (Eigen's reduction of a 2..4-element float vector)."""
+    s = np.float32(0.0)
+    for x in v:
+        s = np.float32(s + np.float32(x))
+    return s
+
+
 def _libm_logf(x: float) -> float:
     return _libm.logf(x)
 
@@ -298,11 +306,11 @@ class TransitionModel:
     def mle_update(self, stats, cfg: MleTransitionUpdateConfig = None):
         """csrc/transition-model.cc:657-750 -> (objf_impr, count)."""
         cfg = cfg or MleTransitionUpdateConfig()
-        if cfg.share_for_pdfs:
-            raise KhgError("share_for_pdfs=True is not implemented on this path")
         st = _lib.as_np(np.asarray(stats), np.float64)
         if st.shape[0] != self.num_transition_ids + 1:
             raise KhgError("stats.size() == NumTransitionIds() + 1 assertion failed")
+        if cfg.share_for_pdfs:
+            return self._mle_update_shared(st, cfg)
         s2i = np.asarray(self._state2id, np.int32)
         slo = np.asarray([0] + [self.self_loop_of(ts) for ts in range(1, self.num_transition_states + 1)], np.int32)
         oi, cnt = C.c_float(), C.c_float()
@@ -311,6 +319,55 @@ class TransitionModel:
                                             ptr(self._log_probs, C.c_float), ptr(self._nsl, C.c_float),
                                             C.byref(oi), C.byref(cnt)))
         return oi.value, cnt.value
+
+    def _mle_update_shared(self, st: np.ndarray, cfg: "MleTransitionUpdateConfig"):
+        """TransitionModel::MleUpdateShared (csrc/transition-model.cc:531-655): one set of transition probabilities for all
+        transition-states that share a pdf.  Arithmetic as there: counts and their total in double, the new probabilities a
+        float vector (normalised and floored three times), the objective change summed in float."""
+        f32 = np.float32
+        groups = {}                                   # pdf -> ordered set of transition-states (std::map<int32, std::set<int32>>)
+        for ts in range(1, self.num_transition_states + 1):
+            t = self._tuples[ts - 1]
+            groups.setdefault(t.forward_pdf, set()).add(ts)
+            if not self._topo.is_hmm:
+                groups.setdefault(t.self_loop_pdf, set()).add(ts)
+        count_sum, objf_sum = f32(0.0), f32(0.0)
+        floor = f32(cfg.floor)
+        for pdf in sorted(groups):
+            tstates = sorted(groups[pdf])
+            one = tstates[0]
+            n = self._state2id[one + 1] - self._state2id[one]
+            if n <= 1:
+                continue
+            counts = np.zeros(n, np.float64)
+            pdf_tot = 0.0
+            for ts in tstates:
+                if self._state2id[ts + 1] - self._state2id[ts] != n:
+                    raise KhgError("Mismatch in #transition indices: you cannot use the --share-for-pdfs option with this topology "
+                                   "and sharing scheme.")
+                for k in range(n):
+                    acc = float(st[self._state2id[ts] + k])
+                    counts[k] += acc
+                    pdf_tot += acc
+            count_sum = f32(np.float64(count_sum) + pdf_tot)          # float += double
+            if pdf_tot < cfg.mincount:
+                continue
+            old = np.array([_libm_expf(float(self._log_probs[self._state2id[one] + k])) for k in range(n)], f32)   # GetTransitionProb
+            new = (counts / pdf_tot).astype(f32)
+            for _ in range(3):                          # keep flooring + renormalising three times
+                new = (new / _f32_sum(new)).astype(f32)
+                new = np.maximum(new, floor)
+            for k in range(n):
+                dlog = f32(f32(_libm_logf(float(new[k]))) - f32(_libm_logf(float(old[k]))))       # std::log(float) is logf
+                objf_sum = f32(np.float64(objf_sum) + counts[k] * np.float64(dlog))                # float += double
+            for ts in tstates:
+                for k in range(n):
+                    lp = _libm_logf(float(new[k]))
+                    if not np.isfinite(lp):
+                        raise KhgError("Log probs is inf or NaN: error in update or bad stats?")
+                    self._log_probs[self._state2id[ts] + k] = lp
+        self._compute_derived_of_probs()
+        return float(objf_sum), float(count_sum)
 
     # ---- helpers for the device path ----
     def is_self_loop_array(self) -> np.ndarray:

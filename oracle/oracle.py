@@ -377,6 +377,53 @@ def transition_mle_update(state2id, self_loop_of, stats, log_probs, nsl, floor=0
     return lp, ns, oi.value, cnt.value
 
 
+def transition_mle_update_shared(state2id, fwd_pdf, stats, log_probs, floor=0.01, mincount=5.0):
+    """TransitionModel::MleUpdateShared (transition-model.cc:531-655) for is_hmm topologies, restated over arrays:
+    state2id[1..S+1] first transition-id of each transition-state, fwd_pdf[1..S] its pdf.  -> (new log_probs, objf_impr, count).
+    (Test infrastructure; the non-self-loop log-probs are re-derived by the caller, transition-model.cc:339-359.)"""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    libm.expf.restype = ctypes.c_float; libm.expf.argtypes = [ctypes.c_float]
+    s2i = np.asarray(state2id, np.int64)
+    S = len(s2i) - 2
+    lp = np.array(log_probs, f32, copy=True)
+    st = np.asarray(stats, np.float64)
+    by_pdf = {}
+    for ts in range(1, S + 1):
+        by_pdf.setdefault(int(fwd_pdf[ts]), []).append(ts)
+    count_sum = f32(0); objf = f32(0)
+    for pdf in sorted(by_pdf):
+        tss = by_pdf[pdf]
+        n = int(s2i[tss[0] + 1] - s2i[tss[0]])
+        if n <= 1:
+            continue
+        if any(int(s2i[t + 1] - s2i[t]) != n for t in tss):
+            raise RuntimeError("Mismatch in #transition indices")
+        rows = np.stack([st[s2i[t]: s2i[t] + n] for t in tss])            # [tstates][n]
+        counts = np.zeros(n, np.float64); tot = 0.0
+        for r in rows:                                                      # the reference's accumulation order
+            for k in range(n):
+                counts[k] += r[k]; tot += r[k]
+        count_sum = f32(np.float64(count_sum) + tot)
+        if tot < mincount:
+            continue
+        old = np.array([libm.expf(float(lp[s2i[tss[0]] + k])) for k in range(n)], f32)
+        new = (counts / tot).astype(f32)
+        for _ in range(3):
+            ssum = f32(0)
+            for x in new:
+                ssum = f32(ssum + x)
+            new = np.maximum((new / ssum).astype(f32), f32(floor))
+        for k in range(n):
+            d = f32(f32(libm.logf(float(new[k]))) - f32(libm.logf(float(old[k]))))
+            objf = f32(np.float64(objf) + counts[k] * np.float64(d))
+        for t in tss:
+            for k in range(n):
+                lp[s2i[t] + k] = libm.logf(float(new[k]))
+    return lp, float(objf), float(count_sum)
+
+
 def augment_gmm_flags(flags):
     return int(lib().orc_augment_gmm_flags(flags))
 

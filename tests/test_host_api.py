@@ -560,3 +560,59 @@ def test_pybind11_module_is_the_host_surface():
     c = ext.scaled_trans_cost(np.asarray(tm.log_probs, np.float32), np.asarray(tm.non_self_loop_log_probs, np.float32),
                               np.asarray(tm.id2state, np.int32), np.asarray([0] + [int(tm.is_self_loop(t)) for t in range(1, tm.num_transition_ids + 1)], np.uint8), 1.0, 0.1)
     np.testing.assert_array_equal(c, tm.scaled_trans_cost(1.0, 0.1))
+
+
+def test_transition_mle_update_shared_for_pdfs():
+    """MleTransitionUpdateConfig(share_for_pdfs=True) (transition-model.cc:531-655): transition-states that share a pdf get ONE
+    set of probabilities from their pooled counts.  Checked against the oracle's restatement bit for bit, and through two
+    properties: with one transition-state per pdf it is the ordinary update (to float rounding of the objective), and with
+    a tree that ties two phones the tied states end up with identical probabilities."""
+    import kaldi_hmm_gmm_amd as khg
+    from kaldi_hmm_gmm_amd.training_graph import generate_hmm_topo
+
+    topo = generate_hmm_topo(non_sil_phones=[2, 3, 4], sil_phone=1)
+    rng = np.random.default_rng(5)
+
+    def model(shared_phones=None):
+        p2n = topo.get_phone_to_num_pdf_classes()
+        tree = khg.monophone_context_dependency_shared(shared_phones, p2n) if shared_phones else khg.monophone_context_dependency(topo.phones, p2n)
+        return khg.TransitionModel(tree, topo)
+
+    # (1) one transition-state per pdf: shared == ordinary
+    tm_a, tm_b = model(), model()
+    stats = rng.uniform(0.0, 40.0, tm_a.num_transition_ids + 1)
+    stats[0] = 0.0
+    stats[tm_a.pair_to_transition_id(3, 0): tm_a.pair_to_transition_id(3, 0) + 2] = [1.0, 0.5]      # below mincount: skipped
+    oa, ca = tm_a.mle_update(stats, khg.MleTransitionUpdateConfig())
+    ob, cb = tm_b.mle_update(stats, khg.MleTransitionUpdateConfig(share_for_pdfs=True))
+    np.testing.assert_allclose(tm_b.log_probs, tm_a.log_probs, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(tm_b.non_self_loop_log_probs, tm_a.non_self_loop_log_probs, rtol=0, atol=1e-6)
+    assert cb == pytest.approx(ca, rel=1e-6) and ob == pytest.approx(oa, rel=1e-4, abs=1e-3)
+    # against the oracle, bit for bit
+    tm_c = model()
+    s2i = np.asarray(tm_c._state2id, np.int64)
+    fwd = np.asarray([0] + [t.forward_pdf for t in tm_c._tuples], np.int64)
+    want_lp, want_o, want_c = orc.transition_mle_update_shared(s2i, fwd, stats, tm_c.log_probs)
+    oc, cc = tm_c.mle_update(stats, khg.MleTransitionUpdateConfig(share_for_pdfs=True))
+    assert np.array_equal(tm_c.log_probs, want_lp) and oc == want_o and cc == want_c
+    # (2) phones 2 and 3 tied by the tree: their states share pdfs -> identical probabilities from pooled counts
+    tm_t = model(shared_phones=[[1], [2, 3], [4]])
+    s2i = np.asarray(tm_t._state2id, np.int64)
+    fwd = np.asarray([0] + [t.forward_pdf for t in tm_t._tuples], np.int64)
+    stats = rng.uniform(5.0, 40.0, tm_t.num_transition_ids + 1)
+    want_lp, want_o, want_c = orc.transition_mle_update_shared(s2i, fwd, stats, tm_t.log_probs)
+    ot, ct = tm_t.mle_update(stats, khg.MleTransitionUpdateConfig(share_for_pdfs=True))
+    assert np.array_equal(tm_t.log_probs, want_lp) and ot == want_o and ct == want_c
+    tied = {}
+    for ts in range(1, tm_t.num_transition_states + 1):
+        tied.setdefault(tm_t._tuples[ts - 1].forward_pdf, []).append(ts)
+    assert any(len(v) > 1 for v in tied.values())
+    for v in tied.values():
+        for ts in v[1:]:
+            n = s2i[ts + 1] - s2i[ts]
+            assert np.array_equal(tm_t.log_probs[s2i[ts]: s2i[ts] + n], tm_t.log_probs[s2i[v[0]]: s2i[v[0]] + n])
+        # pooled counts: exp(log_prob) = sum of counts over the tied states / total (none floored here)
+        n = int(s2i[v[0] + 1] - s2i[v[0]])
+        if n > 1:
+            pooled = sum(stats[s2i[ts]: s2i[ts] + n] for ts in v)
+            np.testing.assert_allclose(np.exp(tm_t.log_probs[s2i[v[0]]: s2i[v[0]] + n]), pooled / pooled.sum(), rtol=1e-6)
