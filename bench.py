@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--batches", type=int, default=1, help="utterance batches per rank (more batches bound the score/back-pointer buffers and let a batch's serial fallback decoder overlap the next batch's K1)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
-    ap.add_argument("--k1", choices=["auto", "f16x2", "bf16x3", "pdf", "utt"], default="auto",
+    ap.add_argument("--k1", choices=["auto", "f16x2s", "f16x2", "bf16x3", "pdf", "utt"], default="auto",
                     help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = f16x2 (fp16 matrix cores at fp32 accuracy, 3 partial "
                          "products); bf16x3 = bf16 matrix cores, 6 partial products; pdf / utt = the fp32-MFMA forms")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the two extra steps that time the fp32-MFMA K1 beside an f16x2 / bf16x3 run")
@@ -86,7 +86,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(frames_per_launch, k1_form="f16x2"):
+def pmc_traffic(frames_per_launch, k1_form="f16x2s"):
     """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction) -- bench.py cannot run the profiler on
     itself.  Only reported when the profile was taken at this launch size AND on these kernel sources (csrc_sha);
@@ -96,7 +96,7 @@ def pmc_traffic(frames_per_launch, k1_form="f16x2"):
         try:
             with open(path) as fh:
                 pm = json.load(fh)
-            want = {"f16x2": "k1h_loglikes", "bf16x3": "k1b_loglikes", "pdf": "k1p_loglikes", "utt": "k1_loglikes"}[k1_form]
+            want = {"f16x2s": "k1s_loglikes", "f16x2": "k1h_loglikes", "bf16x3": "k1b_loglikes", "pdf": "k1p_loglikes", "utt": "k1_loglikes"}[k1_form]
             k1 = next(v for k, v in pm["kernels"].items() if k.startswith(want))
             rel = os.path.relpath(path, ROOT)
             if abs(pm["frames_per_launch"] / frames_per_launch - 1.0) > 0.02:
@@ -260,8 +260,8 @@ def main():
     torch.cuda.set_stream(streams[0])
     ctxs = [Context(local, stream=st.cuda_stream) for st in streams]
     env_k1 = os.environ.get("KHG_K1")
-    k1_form = {"fp32": "pdf"}.get(env_k1, env_k1) if env_k1 in ("f16x2", "bf16x3", "pdf", "utt", "fp32") else ("f16x2" if args.k1 == "auto" else args.k1)
-    split_form = k1_form in ("f16x2", "bf16x3")      # fp32 operands split into 16-bit pieces for the 16-bit matrix cores
+    k1_form = {"fp32": "pdf"}.get(env_k1, env_k1) if env_k1 in ("f16x2s", "f16x2", "bf16x3", "pdf", "utt", "fp32") else ("f16x2s" if args.k1 == "auto" else args.k1)
+    split_form = k1_form in ("f16x2s", "f16x2", "bf16x3")      # fp32 operands split into 16-bit pieces for the 16-bit matrix cores
     for c in ctxs:
         c.set_k1_form(k1_form)
     dm = DeviceModel(ctxs[0], model.gauss_off, gc, model.means_invvars, model.inv_vars)
@@ -298,7 +298,9 @@ def main():
             poff_, _ = s_.pdf_lists()
             first = s_.pdf_first_frames().astype(np.int64)
             Tu = np.repeat(np.diff(s_.frame_off), np.diff(poff_))
-            if split_form:                          # whole 32-frame tiles (first needed 16-frame tile, clamped to 127, halved)
+            if k1_form == "f16x2s":                 # whole 32-frame tiles (first needed 32-frame tile, clamped to 255)
+                skipped_cells += float(np.minimum(32 * np.minimum(first // 32, 255), Tu).sum())
+            elif split_form:                        # whole 32-frame tiles (first needed 16-frame tile, clamped to 127, halved)
                 skipped_cells += float(np.minimum(32 * (np.minimum(first // 16, 127) // 2), Tu).sum())
             else:
                 skipped_cells += float(np.minimum(16 * (first // 16), Tu).sum())
@@ -335,8 +337,20 @@ def main():
             e1.record(streams[0])
             ar_events.append((e0, e1))
 
-    for _ in range(args.warmup):
+    # Work done ONCE per utterance set / parameter version, outside the timed region: the column maxima behind K1's scale
+    # exponents, the fp16 feature planes, the model's fp16 image.  Its kernels are timed during the first warm-up step.
+    prep_ms = {}
+    for w in range(args.warmup):
+        if w == 0:
+            for c in ctxs:
+                c.sync(); c.set_timing(True)
         step()
+        if w == 0:
+            for c in ctxs:
+                for name, ms in c.timings():
+                    if name in ("k1_absmax", "k1s_pack_x", "k0s_pack_tiles", "k1h_pack_x", "k0h_pack_tiles", "k0b_pack_tiles"):
+                        prep_ms[name] = prep_ms.get(name, 0.0) + ms
+                c.set_timing(False)
     torch.cuda.synchronize()
     ar_events.clear()
     for c in ctxs:
@@ -458,9 +472,10 @@ def main():
             # every fp32 multiply-add of the contraction is NPROD 16-bit multiply-adds (3: khg_k1_f16x2.hip.inc, 6:
             # khg_k1_bf16x3.hip.inc): the 16-bit FLOPs of the SURVEY 8(d) contract are cells x (NPROD x 4DG + 5G), priced against
             # the dense fp16 / bf16 MFMA peak (the same 2.5 PFLOP/s)
-            nprod = 3 if k1_form == "f16x2" else 6
+            nprod = 3 if k1_form in ("f16x2s", "f16x2") else 6
             bflops = cells * (nprod * 4.0 * D * G + 5.0 * G)
-            kname = ("k1h_loglikes: v_mfma_f32_32x32x16_f16, f16x2" if k1_form == "f16x2" else "k1b_loglikes: v_mfma_f32_32x32x16_bf16, bf16x3")
+            kname = {"f16x2s": "k1s_loglikes: v_mfma_f32_32x32x16_f16, f16x2s", "f16x2": "k1h_loglikes: v_mfma_f32_32x32x16_f16, f16x2",
+                     "bf16x3": "k1b_loglikes: v_mfma_f32_32x32x16_bf16, bf16x3"}[k1_form]
             roofline = {"bound": "mfma", "kernel": "k1_loglikes (%s)" % kname, "achieved": bflops / t_k1 / 1e12,
                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bflops / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                         "frac_executed": bflops * k1_exec_frac / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
@@ -472,9 +487,10 @@ def main():
                         "executed_cell_fraction": k1_exec_frac,
                         "note": "achieved/frac: 16-bit FLOPs of the dense T x P_u contract (%d partial products per fp32 product) / kernel time "
                                 "/ the 2.5 PFLOP/s dense fp16 = bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame "
-                                "tiles (executed_cell_fraction); frac_executed = frac x that fraction.  Under a bare 16-bit MFMA loop this chip "
-                                "holds 1.8 GHz = 1.8 PFLOP/s (tools/mfma_bf16_chain.hip), 0.72 of the spec peak.  With 3 products the log-sum-exp "
-                                "(VALU, ~90 instructions per 15 MFMAs) shares the issue port with the MFMAs about evenly" % nprod,
+                                "tiles (executed_cell_fraction); frac_executed = frac x that fraction.  K1 is bound by POWER: under a bare "
+                                "dependent 16-bit MFMA loop the chip holds 1.5-1.8 GHz (18.7-21.5 ns per v_mfma_f32_32x32x16 and SIMD on the boxes "
+                                "of this pool, tools/k1lab.hip: 0.60-0.72 of the 2.5 PFLOP/s spec peak), and every byte moved and VALU "
+                                "instruction issued beside the MFMAs lowers the clock further" % nprod,
                         "kernel_ms": k1_avg_ms, "flops_per_launch": bflops, "launches_per_step": nb}
         else:
             ach = k1_flops_per_launch / t_k1 / 1e12
@@ -499,12 +515,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if not split_form else "f32 via " + k1_form,
             "dtype_note": None if not split_form else (
+                "log-likelihood contraction: fp32 operands rescaled per k by an exact power of two and split into two fp16 pieces (11 + 11 "
+                "significant bits: |v - (v1 + v2)| <= max(2^-23 |v|, 2^-25) in scaled units), the three partial products w1 x1, w1 x2, "
+                "w2 x1 on the fp16 matrix cores into ONE fp32 accumulator; the dropped w2 x2 is <= 2^-22 of the term, worst case 2^-21 per "
+                "term plus an absolute floor the library keeps under 2e-6 (else it runs the two-accumulator f16x2 form, else fp32 MFMA); "
+                "measured error vs fp64: max 2.1e-7 B (tools/k1lab.hip; the fp32 fmaf chain of the fp32-MFMA kernels: 7.4e-7 B), every "
+                "fp64-bound tolerance test (1e-5 + 1e-6 B) unchanged; everything else fp32 / fp64 as the reference; the fp32-MFMA K1 is "
+                "timed beside it in fp32_mfma_line (--k1 pdf runs it as the whole bench)" if k1_form == "f16x2s" else
                 "log-likelihood contraction: fp32 operands rescaled per k by an exact power of two and written as v1 + v2 2^-11 with two fp16 "
-                "pieces (|v - (v1 + v2 2^-11)| <= 2^-24 |v|), the three partial products w1 x1, w1 x2, w2 x1 on the fp16 matrix cores with "
-                "fp32 accumulators -- worst case 3 x 2^-24 per term, measured error vs fp64 BELOW the fp32 fmaf chain's (max 3.0e-7 B vs "
-                "7.4e-7 B, profiles/r2_probe_f16x2.txt), every fp64-bound tolerance test unchanged; models whose operands do not fit fp16 "
-                "under any scaling run the bf16x3 form; everything else fp32 / fp64 as the reference; the fp32-MFMA K1 is timed beside it "
-                "in fp32_mfma_line (--k1 pdf runs it as the whole bench)" if k1_form == "f16x2" else
+                "pieces (|v - (v1 + v2 2^-11)| <= 2^-23 |v|: 11 + 11 significant bits), the three partial products w1 x1, w1 x2, w2 x1 on the "
+                "fp16 matrix cores with fp32 accumulators; the dropped w2 x2 is <= 2^-22 of the term -- worst case 2^-21 per term, measured "
+                "error vs fp64 max 3.0e-7 B (the fp32 fmaf chain: 7.4e-7 B, profiles/r2_probe_f16x2.txt), every fp64-bound tolerance test "
+                "unchanged; everything else fp32 / fp64 as the reference; the fp32-MFMA K1 is timed beside it in fp32_mfma_line "
+                "(--k1 pdf runs it as the whole bench)" if k1_form == "f16x2" else
                 "log-likelihood contraction: fp32 operands split EXACTLY into three bf16 pieces, the six partial products of weight >= 2^-16 on "
                 "the bf16 matrix cores, fp32 accumulate -- measured error vs fp64 BELOW the fp32 fmaf chain's (max 4.4e-7 B vs 6.0e-7 B, "
                 "profiles/r2_probe_bf16x3.txt), every fp64-bound tolerance test unchanged; everything else fp32 / fp64 as the reference; the "
@@ -517,6 +540,9 @@ def main():
             "roofline": roofline,
             "fp32_mfma_line": fp32_line,
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
+            "prep_ms": {"kernels": prep_ms, "total": sum(prep_ms.values()),
+                        "note": "once per utterance set (column maxima, fp16 feature planes) / per parameter version (fp16 model image): "
+                                "outside the timed region, measured during the first warm-up step"},
             "allreduce_ms_per_step": (sum(a_.elapsed_time(b_) for a_, b_ in ar_events) / max(len(ar_events), 1)) if ar_events else None,
             "allreduce_bytes": int(accs.size) * 8 if dist_on else None,
             "m_step": m_step,

@@ -69,6 +69,7 @@ int khg_ctx_get_timings(khg_ctx *ctx, char *names, int64_t names_cap, float *ms,
 #define KHG_K1_FP32_PDF 2
 #define KHG_K1_FP32_UTT 3
 #define KHG_K1_F16X2 4
+#define KHG_K1_F16X2S 5
 int khg_ctx_set_k1_form(khg_ctx *ctx, int form);
 
 /* ---- acoustic model ------------------------------------------------------------------- */

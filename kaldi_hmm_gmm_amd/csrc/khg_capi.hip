@@ -15,6 +15,7 @@
 #include <string>
 #include <type_traits>
 #include <deque>
+#include <utility>
 #include <vector>
 
 #include "../../include/khg_hip.h"
@@ -23,6 +24,7 @@
 #include "khg_k1_pdfmajor.hip.inc"
 #include "khg_k1_bf16x3.hip.inc"
 #include "khg_k1_f16x2.hip.inc"
+#include "khg_k1_f16x2s.hip.inc"
 #include "khg_k2_viterbi.hip.inc"
 #include "khg_k3_accstats.hip.inc"
 #include "khg_k4_mstep.hip.inc"
@@ -49,6 +51,7 @@ struct khg_ctx {
   int next_side = 0;
   bool own_stream = false;
   int32_t* err_flag_d = nullptr;
+  float* dump_d = nullptr;          // 256 floats nobody reads (K1 f16x2s: where the pipeline's first, empty value goes)
   bool timing = false;
   std::vector<khg_timing> timings;
   int k1_form = KHG_K1_AUTO;      // khg_ctx_set_k1_form; the KHG_K1 environment variable overrides it
@@ -100,6 +103,7 @@ extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
   else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   for (auto& s : c->sides) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   int rc = dev_alloc(&c->err_flag_d, 1);
+  if (!rc) rc = dev_alloc(&c->dump_d, 256);
   if (rc) { delete c; return rc; }
   HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
   *out = c;
@@ -109,7 +113,7 @@ extern "C" int khg_ctx_destroy(khg_ctx* c) {
   if (!c) return KHG_OK;
   (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->sides) (void)hipStreamSynchronize(s);
-  DEVFREE(c->err_flag_d);
+  DEVFREE(c->err_flag_d); DEVFREE(c->dump_d);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   for (auto& s : c->sides) (void)hipStreamDestroy(s);
   delete c;
@@ -140,7 +144,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
   return KHG_OK;
 }
 extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) {
-  if (!c || form < KHG_K1_AUTO || form > KHG_K1_F16X2) return khg_set_error(KHG_E_ARG, "khg_ctx_set_k1_form: bad arguments");
+  if (!c || form < KHG_K1_AUTO || form > KHG_K1_F16X2S) return khg_set_error(KHG_E_ARG, "khg_ctx_set_k1_form: bad arguments");
   c->k1_form = form;
   return KHG_OK;
 }
@@ -198,6 +202,43 @@ __global__ __launch_bounds__(256) void k0_pack_tiles(const float* __restrict__ g
   for (int i = threadIdx.x; i < nrow * D; i += 256) nhiv[(size_t)g_first * D + i] = -0.5f * iv[(size_t)g_first * D + i];
 }
 
+// A model image that K1 launches on several contexts' streams read and that is re-packed in place when the parameters or the
+// scale exponents change: the pack waits for every recorded reader, a reader on another stream waits for the pack.
+struct ImgSync {
+  hipEvent_t packed = nullptr;
+  hipStream_t pack_stream = nullptr;
+  std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
+  int before_pack(hipStream_t s) {
+    for (auto& r : readers)
+      if (r.first != s) HIPCHK(hipStreamWaitEvent(s, r.second, 0));
+    return KHG_OK;
+  }
+  int after_pack(hipStream_t s) {
+    if (!packed) HIPCHK(hipEventCreateWithFlags(&packed, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(packed, s));
+    pack_stream = s;
+    return KHG_OK;
+  }
+  int before_read(hipStream_t s) {
+    if (packed && pack_stream != s) HIPCHK(hipStreamWaitEvent(s, packed, 0));
+    return KHG_OK;
+  }
+  int after_read(hipStream_t s) {
+    for (auto& r : readers)
+      if (r.first == s) { HIPCHK(hipEventRecord(r.second, s)); return KHG_OK; }
+    hipEvent_t e = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e, s));
+    readers.emplace_back(s, e);
+    return KHG_OK;
+  }
+  void destroy() {
+    if (packed) (void)hipEventDestroy(packed);
+    for (auto& r : readers) (void)hipEventDestroy(r.second);
+    packed = nullptr; readers.clear();
+  }
+};
+
 // ------------------------------------------------------------------------------------------
 struct khg_model {
   khg_ctx* ctx = nullptr;
@@ -218,6 +259,12 @@ struct khg_model {
   char* wimgh_d = nullptr;
   int32_t wimgh_tiles = 0;
   std::vector<int32_t> wimgh_ex;   // exponents the image was packed with (empty: stale)
+  ImgSync wimgh_sync, wimgb_sync;
+  // f16x2s K1 image (khg_k1_f16x2s.hip.inc): packed lazily with the weight exponents ew[k] = S - ex[k] and gconst 2^S
+  char* wimgs_d = nullptr;
+  int32_t wimgs_tiles = 0;
+  std::vector<int32_t> wimgs_key;  // [ex[0..K) of the set, S] the image was packed with (empty: stale)
+  ImgSync wimgs_sync;
   std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
   float gcmax = 0.0f;              // max |gconst| over the finite ones (valid with wmax)
   int32_t* tile_pdf_d = nullptr;   // tile -> pdf map of the current layout
@@ -252,6 +299,7 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
   DEVFREE(m->tile_pdf_d);
   m->wimgh_ex.clear();
+  m->wimgs_key.clear();
   m->wmax.clear();
   int rc = dev_upload(ctx, &m->tile_pdf_d, tile_pdf);
   int32_t* tile_pdf_d = m->tile_pdf_d;
@@ -298,7 +346,8 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 }
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
@@ -381,6 +430,11 @@ struct khg_utts {
   // K1, f16x2 form: B fragments packed with the scale exponents xh_ex (per k = 2 d + kind)
   k1b_u32x4* xh_d = nullptr; int32_t xh_ks = 0; std::vector<int32_t> xh_ex; int32_t* xh_ex_d = nullptr;
   std::vector<float> xmax;         // per feature dimension: max |x| over the set (empty: not computed)
+  // K1, f16x2s form: B fragments packed once with the set's own exponents xs_ex (feature columns peak in [2^14, 2^15)),
+  // workgroup chunks of <= k1s_nmax tiles, one unit per (utterance, listed pdf)
+  k1b_u32x4* xs_d = nullptr; int32_t xs_ks = 0; std::vector<int32_t> xs_ex; int32_t* xs_ex_d = nullptr;
+  K1sChunk* schunks_d = nullptr; int32_t n_schunks = 0, schunk_nmax = 0;
+  K1sUnit* sunits_d = nullptr; std::vector<int32_t> sunits_pto; int sunits_reach = -1;
   // K2 scratch / outputs
   uint8_t* bp_d = nullptr; int64_t *bp_off_d = nullptr, *path_off_d = nullptr, *words_off_d = nullptr;
   double* layer_best_d = nullptr; int32_t* layer_cnt_d = nullptr; int32_t* path_d = nullptr;
@@ -588,6 +642,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
   DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d); DEVFREE(u->xh_d); DEVFREE(u->xh_ex_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
+  DEVFREE(u->xs_d); DEVFREE(u->xs_ex_d); DEVFREE(u->schunks_d); DEVFREE(u->sunits_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d); DEVFREE(u->k2_order_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
@@ -769,45 +824,54 @@ static int ensure_walk(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reach
   return KHG_OK;
 }
 
-// 32-frame tile layout of the set shared by the bf16x3 and f16x2 forms: tile offsets per utterance, tile -> utterance,
-// workgroup chunks of <= 8 NTMAX tiles.
-static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
-  if (u->utt_x32_off_d && u->bchunk_nt == NTMAX) return KHG_OK;
-  DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d);
-  DEVFREE(u->xb3_d); DEVFREE(u->xh_d);
-  u->xb3_ks = 0; u->xh_ks = 0;
+// 32-frame tile layout of the set shared by the bf16x3 / f16x2 / f16x2s forms: tile offsets per utterance, tile -> utterance.
+static int ensure_x32_layout(khg_ctx* ctx, khg_utts* u) {
+  if (u->utt_x32_off_d) return KHG_OK;
   std::vector<int64_t> xoff((size_t)u->n_utt + 1, 0);
   for (int i = 0; i < u->n_utt; ++i) xoff[(size_t)i + 1] = xoff[(size_t)i] + (u->frame_off[i + 1] - u->frame_off[i] + 31) / 32;
   const int64_t nx = xoff[(size_t)u->n_utt];
   std::vector<int32_t> xutt((size_t)nx);
-  std::vector<K1bChunk> ch;
-  const int per = 8 * NTMAX;
-  for (int i = 0; i < u->n_utt; ++i) {
-    const int n32 = (int)(xoff[(size_t)i + 1] - xoff[(size_t)i]);
+  for (int i = 0; i < u->n_utt; ++i)
     for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
+  int rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
+  if (!rc) rc = dev_upload(ctx, &u->x32_utt_d, xutt);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  u->n_x32 = nx;
+  return KHG_OK;
+}
+// Workgroup chunks of <= `per` 32-frame tiles: an utterance is cut into equal parts (a 17-tile utterance becomes 9 + 8 tiles, not
+// 16 + 1), and the chunks are launched longest first (duration ~ frame tiles x pdfs): the workgroups still running when the grid
+// drains are then the short ones (a launch of 12 500 utterances -- the 8-GPU shard -- is ~49 rounds of workgroups whose durations
+// differ 4x).  K1bChunk and K1sChunk have the same layout.
+template <class Chunk>
+static void plan_x32_chunks(const khg_utts* u, int per, std::vector<Chunk>* ch) {
+  ch->clear();
+  for (int i = 0; i < u->n_utt; ++i) {
+    const int n32 = (int)((u->frame_off[i + 1] - u->frame_off[i] + 31) / 32);
     if (u->pdf_off[i + 1] == u->pdf_off[i]) continue;
-    // chunks of equal size (a 17-tile utterance becomes 9 + 8 tiles, not 16 + 1)
     const int nch = (n32 + per - 1) / per;
     for (int c = 0; c < nch; ++c) {
       const int t0 = (int)((int64_t)n32 * c / nch), t1 = (int)((int64_t)n32 * (c + 1) / nch);
-      if (t1 > t0) ch.push_back(K1bChunk{i, t0, t1 - t0, 0});
+      if (t1 > t0) ch->push_back(Chunk{i, t0, t1 - t0, 0});
     }
   }
-  // longest chunks first: the workgroups still running when the grid drains are then the short ones (a launch of 12 500
-  // utterances -- the 8-GPU shard -- is ~49 rounds of workgroups whose durations differ 4x)
-  // (duration ~ frame tiles x pdfs of the utterance)
-  {
-    const char* oe = getenv("KHG_K1_ORDER");     // experiments: none | asc | tiles (default: frame tiles x pdfs, descending)
-    auto cost = [&](const K1bChunk& c) { return (int64_t)c.ntiles * ((oe && strcmp(oe, "tiles") == 0) ? 1 : (u->pdf_off[c.utt + 1] - u->pdf_off[c.utt])); };
-    if (oe && strcmp(oe, "asc") == 0) std::stable_sort(ch.begin(), ch.end(), [&](const K1bChunk& a, const K1bChunk& b) { return cost(a) < cost(b); });
-    else if (!(oe && strcmp(oe, "none") == 0)) std::stable_sort(ch.begin(), ch.end(), [&](const K1bChunk& a, const K1bChunk& b) { return cost(a) > cost(b); });
-  }
-  int rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
-  if (!rc) rc = dev_upload(ctx, &u->x32_utt_d, xutt);
-  if (!rc) rc = dev_upload(ctx, &u->bchunks_d, ch);
+  const char* oe = getenv("KHG_K1_ORDER");     // experiments: none | asc | tiles (default: frame tiles x pdfs, descending)
+  auto cost = [&](const Chunk& c) { return (int64_t)c.ntiles * ((oe && strcmp(oe, "tiles") == 0) ? 1 : (u->pdf_off[c.utt + 1] - u->pdf_off[c.utt])); };
+  if (oe && strcmp(oe, "asc") == 0) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) < cost(b); });
+  else if (!(oe && strcmp(oe, "none") == 0)) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) > cost(b); });
+}
+static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
+  int rc = ensure_x32_layout(ctx, u);
+  if (rc) return rc;
+  if (u->bchunks_d && u->bchunk_nt == NTMAX) return KHG_OK;
+  DEVFREE(u->bchunks_d);
+  std::vector<K1bChunk> ch;
+  plan_x32_chunks(u, 8 * NTMAX, &ch);
+  rc = dev_upload(ctx, &u->bchunks_d, ch);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  u->n_x32 = nx; u->n_bchunks = (int32_t)ch.size(); u->bchunk_nt = NTMAX;
+  u->n_bchunks = (int32_t)ch.size(); u->bchunk_nt = NTMAX;
   return KHG_OK;
 }
 
@@ -873,6 +937,7 @@ static int absmax_cols(khg_ctx* ctx, const float* a_d, int64_t n, int D, std::ve
   hipError_t e = hipMemsetAsync(m_d, 0, 128 * sizeof(uint32_t), ctx->stream);
   if (e == hipSuccess && n > 0) {
     const int gb = (int)std::min<int64_t>(4096, (n + 1) / 2);
+    KernelTimer kt(ctx, "k1_absmax");
     hipLaunchKernelGGL(k1h_absmax, dim3(gb), dim3(256), 0, ctx->stream, a_d, n, D, m_d);
     e = hipGetLastError();
   }
@@ -1034,6 +1099,133 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
   return KHG_OK;
 }
 
+// K1 on the fp16 matrix cores, one accumulator per chain, transposed decomposition (khg_k1_f16x2s.hip.inc; the default).
+// -> KHG_OK, an error, or +1: outside this form's domain (the caller tries the two-accumulator f16x2 form next).
+static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachable_only) {
+  const int KS = m->KS, D = m->D, K = 16 * KS, NMAX = k1s_nmax(KS);
+  std::vector<float> xk;
+  int rc = k1_maxima(ctx, m, u, &xk);
+  if (rc) return rc;
+  if (!k1_split_domain(m, xk)) return 1;
+  // exponents: every feature column peaks in [2^14, 2^15) (the set's own property), the largest weight column too (S)
+  std::vector<int32_t> ex((size_t)K, 0), ew((size_t)K, 0);
+  for (int k = 0; k < K; ++k) if (xk[(size_t)k] > 0.0f) ex[(size_t)k] = 14 - std::ilogb(xk[(size_t)k]);
+  int S = INT_MAX;
+  for (int k = 0; k < K; ++k) if (m->wmax[(size_t)k] > 0.0f) S = std::min(S, 14 - std::ilogb(m->wmax[(size_t)k]) + ex[(size_t)k]);
+  if (S == INT_MAX) S = 0;
+  if (S < -100 || S > 100) return 1;
+  double floor_sum = 0.0;      // the absolute part of the error bound, at the column maxima (khg_k1_f16x2s.hip.inc)
+  for (int k = 0; k < K; ++k) {
+    ew[(size_t)k] = S - ex[(size_t)k];
+    floor_sum += std::ldexp((double)m->wmax[(size_t)k], ew[(size_t)k]) + std::ldexp((double)xk[(size_t)k], ex[(size_t)k]);
+  }
+  floor_sum = std::ldexp(floor_sum, -25 - S);
+  if (!(floor_sum <= 2.0e-6)) return 1;
+  rc = ensure_x32_layout(ctx, u);
+  if (rc) return rc;
+  if (!u->schunks_d || u->schunk_nmax != NMAX) {
+    DEVFREE(u->schunks_d);
+    std::vector<K1sChunk> ch;
+    plan_x32_chunks(u, NMAX, &ch);
+    rc = dev_upload(ctx, &u->schunks_d, ch);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u->n_schunks = (int32_t)ch.size(); u->schunk_nmax = NMAX;
+  }
+  // the set's B fragments: packed once (the exponents depend on the features alone)
+  if (!u->xs_d || u->xs_ks != KS || u->xs_ex != ex) {
+    const int64_t nx = u->n_x32;
+    if (!u->xs_d || u->xs_ks != KS) {
+      DEVFREE(u->xs_d);
+      rc = dev_alloc(&u->xs_d, (size_t)std::max<int64_t>(nx, 1) * 2 * KS * 64);
+      if (rc) return rc;
+    }
+    DEVFREE(u->xs_ex_d);
+    rc = dev_upload(ctx, &u->xs_ex_d, ex);
+    if (rc) return rc;
+    if (nx > 0) {
+      KernelTimer kt(ctx, "k1s_pack_x");
+      const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
+      if (KS == 5) hipLaunchKernelGGL(k1s_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
+      else hipLaunchKernelGGL(k1s_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));    // `ex` (pageable) is free after this
+    u->xs_ks = KS; u->xs_ex = ex;
+  }
+  // the model's image for these exponents
+  std::vector<int32_t> key(ex);
+  key.push_back(S);
+  if (m->wimgs_key != key) {
+    rc = m->wimgs_sync.before_pack(ctx->stream);
+    if (rc) return rc;
+    if (!m->wimgs_d || m->wimgs_tiles < m->ntiles) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));     // (the waits on other streams' readers were enqueued above)
+      DEVFREE(m->wimgs_d);
+      rc = dev_alloc(&m->wimgs_d, (size_t)m->ntiles * k1s_tile_bytes(KS));
+      if (rc) return rc;
+      m->wimgs_tiles = m->ntiles;
+    }
+    int32_t* ew_d = nullptr;
+    rc = dev_upload(ctx, &ew_d, ew);
+    if (rc) return rc;
+    const float gscale = std::ldexp(1.0f, S);
+    {
+      KernelTimer kt(ctx, "k0s_pack_tiles");
+      if (KS == 5) hipLaunchKernelGGL(k0s_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, ew_d, gscale, m->wimgs_d);
+      else hipLaunchKernelGGL(k0s_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, ew_d, gscale, m->wimgs_d);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // `ew` (pageable) and ew_d are free after this
+    DEVFREE(ew_d);
+    if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    rc = m->wimgs_sync.after_pack(ctx->stream);
+    if (rc) return rc;
+    m->wimgs_key = key;
+  }
+  // one unit per (utterance, listed pdf): first W tile, number of W tiles, first needed 32-frame tile
+  if (u->sunits_pto != m->pdf_tile_off || u->sunits_reach != (int)reachable_only) {
+    DEVFREE(u->sunits_d);
+    std::vector<K1sUnit> units(u->pdfs.size());
+    for (size_t k = 0; k < u->pdfs.size(); ++k) {
+      const int p = u->pdfs[k];
+      const int nt = m->pdf_tile_off[p + 1] - m->pdf_tile_off[p];
+      if (nt > 0xffff) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: a pdf of more than 2M Gaussians");
+      const int need = reachable_only ? (int)std::min<int64_t>(255, (int64_t)u->pdf_first[k] / 32) : 0;
+      units[k] = K1sUnit{m->pdf_tile_off[p], nt | (need << 16)};
+    }
+    rc = dev_upload(ctx, &u->sunits_d, units);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u->sunits_pto = m->pdf_tile_off;
+    u->sunits_reach = (int)reachable_only;
+  }
+  K1sArgs a;
+  a.xs = u->xs_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->schunks_d;
+  a.wimg = m->wimgs_d; a.pdf_off = u->pdf_off_d; a.units = u->sunits_d;
+  a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.dump = ctx->dump_d; a.err_flag = ctx->err_flag_d;
+  a.c1 = std::ldexp(1.44269504088896340736f, -S);
+  a.inv_scale = std::ldexp(1.0f, -S);
+  a.mfloor = -3.0e38f / std::max(1.0f, a.c1);
+  if (u->n_schunks > 0) {
+    rc = m->wimgs_sync.before_read(ctx->stream);
+    if (rc) return rc;
+    const size_t lds = (size_t)NMAX * k1s_xtile_bytes(KS);
+    const void* fn = KS == 5 ? (const void*)k1s_loglikes<5> : (const void*)k1s_loglikes<10>;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      KernelTimer kt(ctx, "k1_loglikes");
+      if (KS == 5) hipLaunchKernelGGL((k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      else hipLaunchKernelGGL((k1s_loglikes<10>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    rc = m->wimgs_sync.after_read(ctx->stream);
+    if (rc) return rc;
+  }
+  u->ll_valid = true;
+  return KHG_OK;
+}
+
 static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
   if (u->pdf_first.size() != u->pdfs.size()) reachable_only = false;
@@ -1056,11 +1248,17 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     if (const char* env = getenv("KHG_K1")) {
       if (strcmp(env, "bf16x3") == 0) form = KHG_K1_BF16X3;
       else if (strcmp(env, "f16x2") == 0) form = KHG_K1_F16X2;
+      else if (strcmp(env, "f16x2s") == 0) form = KHG_K1_F16X2S;
       else if (strcmp(env, "pdf") == 0 || strcmp(env, "fp32") == 0) form = KHG_K1_FP32_PDF;
       else if (strcmp(env, "utt") == 0) form = KHG_K1_FP32_UTT;
     }
-    if (form == KHG_K1_AUTO) form = KHG_K1_F16X2;
+    if (form == KHG_K1_AUTO) form = KHG_K1_F16X2S;
     if (u->N == 0 || u->pdfs.empty()) { u->ll_valid = true; return KHG_OK; }
+    if (form == KHG_K1_F16X2S) {
+      rc = loglikes_f16x2s(ctx, const_cast<khg_model*>(m), u, reachable_only);
+      if (rc <= 0) return rc;
+      form = KHG_K1_F16X2;           // the absolute part of its error bound is too large for this model: two accumulators
+    }
     if (form == KHG_K1_F16X2) {
       rc = loglikes_f16x2(ctx, const_cast<khg_model*>(m), u, reachable_only);
       if (rc <= 0) return rc;

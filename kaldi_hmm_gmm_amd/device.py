@@ -32,7 +32,7 @@ class Context:
     def sync(self):
         check(lib.khg_ctx_sync(self.h))
 
-    K1_FORMS = {"auto": 0, "bf16x3": 1, "fp32": 2, "pdf": 2, "utt": 3, "f16x2": 4}
+    K1_FORMS = {"auto": 0, "bf16x3": 1, "fp32": 2, "pdf": 2, "utt": 3, "f16x2": 4, "f16x2s": 5}
 
     def set_k1_form(self, form: str):
         """Arithmetic / tiling of the log-likelihood kernel (khg_ctx_set_k1_form): "auto" (= "bf16x3"), "bf16x3", "pdf"

@@ -28,7 +28,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     d = _run({}, "--cpu-baseline-seconds", "3")
     assert KEYS <= set(d), KEYS - set(d)
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["higher_is_better"] is True
-    assert d["value"] > 1e6 and d["ms_per_step"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32 via f16x2" and d["dtype_note"]
+    assert d["value"] > 1e6 and d["ms_per_step"] > 0 and d["vs_baseline"] is None and d["dtype"] == "f32 via f16x2s" and d["dtype_note"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] < 1.0 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert rf["peak"] == 2500.0 and rf["fp32_equivalent"]["peak"] == 157.3 and 0.0 < rf["frac_executed"] <= rf["frac"]

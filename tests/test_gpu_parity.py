@@ -54,7 +54,7 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged, k1_form):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
-@pytest.mark.parametrize("k1", ["f16x2", "bf16x3", "pdf", "utt"])
+@pytest.mark.parametrize("k1", ["f16x2s", "f16x2", "bf16x3", "pdf", "utt"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (24, 20, 13), (12, 128, 80)])
 def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
     """Same bound with the means pulled together (many components contribute to every log-sum-exp instead of one)."""
@@ -88,10 +88,11 @@ def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
     assert np.mean(spread) > 0.5
 
 
-@pytest.fixture(params=["f16x2", "bf16x3", "pdf", "utt"])
+@pytest.fixture(params=["f16x2s", "f16x2", "bf16x3", "pdf", "utt"])
 def k1_form(request, monkeypatch):
-    """Every K1 form: f16x2 (the default: fp16 matrix cores at fp32 accuracy, 3 partial products), bf16x3 (bf16 matrix
-    cores, 6 partial products) and the two fp32-MFMA tilings, pdf-major and utterance-major."""
+    """Every K1 form: f16x2s (the default: fp16 matrix cores, 3 partial products into one accumulator, feature tiles in LDS and
+    pdfs dealt to waves), f16x2 (the same products, two accumulators, frame tiles dealt to waves), bf16x3 (bf16 matrix cores, 6
+    partial products) and the two fp32-MFMA tilings, pdf-major and utterance-major."""
     monkeypatch.setenv("KHG_K1", request.param)
     return request.param
 
@@ -143,7 +144,7 @@ def test_loglikes_f16x2_rescale_and_fallback(ctx, monkeypatch):
     import dataclasses
     from kaldi_hmm_gmm_amd import DeviceModel
 
-    monkeypatch.delenv("KHG_K1", raising=False)
+    monkeypatch.setenv("KHG_K1", "f16x2")
     m, gc, om, ut, cost = build(16, 64, 40, n_utt=5, seed=3, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
     ctx.set_timing(True)
@@ -180,6 +181,46 @@ def test_loglikes_f16x2_rescale_and_fallback(ctx, monkeypatch):
     _check_ll(us, dm_d, m_d, gc_d, ut)
     k = kernels()
     assert "k1h_pack_x" not in k and "k0h_pack_tiles" not in k and "k1_loglikes" in k
+    ctx.set_timing(False)
+
+
+def test_loglikes_f16x2s_planes_packed_once_and_fallback(ctx, monkeypatch):
+    """The default form (f16x2s) packs the set's feature planes ONCE -- their exponents depend on the features alone --, re-packs
+    only the W image for a new model, and hands over to the two-accumulator f16x2 form when the absolute part of its error bound
+    (residual pieces on fp16's subnormal grid) would exceed 2e-6 for the model at hand; results stay inside the fp32 bound."""
+    import dataclasses
+    from kaldi_hmm_gmm_amd import DeviceModel
+
+    monkeypatch.delenv("KHG_K1", raising=False)
+    m, gc, om, ut, cost = build(16, 64, 40, n_utt=5, seed=3, max_phones=5)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    ctx.set_timing(True)
+    ctx.timings()
+
+    def kernels():
+        ctx.sync()
+        return [n for n, _ in ctx.timings()]
+
+    _check_ll(us, dm, m, gc, ut)
+    k = kernels()
+    assert "k1s_pack_x" in k and "k0s_pack_tiles" in k and "k1h_pack_x" not in k
+    m_b = dataclasses.replace(m, means_invvars=(m.means_invvars * 1.25).astype(np.float32))
+    gc_b = orc.model_gconsts(m_b.gauss_off, m_b.weights, m_b.inv_vars, m_b.means_invvars)
+    dm_b = DeviceModel(ctx, m_b.gauss_off, gc_b, m_b.means_invvars, m_b.inv_vars)
+    _check_ll(us, dm_b, m_b, gc_b, ut)
+    k = kernels()
+    assert "k1s_pack_x" not in k and "k0s_pack_tiles" in k
+    _check_ll(us, dm, m, gc, ut)           # the first model again: its image is still valid
+    k = kernels()
+    assert "k0s_pack_tiles" not in k and "k1s_pack_x" not in k
+    # inverse variances x 1e6 in one dimension: the largest weight column then pushes the common scale S down and the floor of the
+    # bound up -> the two-accumulator form (pre-scaled residuals) runs instead
+    s = np.ones(40); s[5] = 1e-3
+    m_c, gc_c, _ = _rescaled(m, ut, s)
+    dm_c = DeviceModel(ctx, m_c.gauss_off, gc_c, m_c.means_invvars, m_c.inv_vars)
+    _check_ll(us, dm_c, m_c, gc_c, ut)
+    k = kernels()
+    assert "k1h_pack_x" in k and "k0h_pack_tiles" in k and "k0s_pack_tiles" not in k
     ctx.set_timing(False)
 
 
