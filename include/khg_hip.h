@@ -53,24 +53,54 @@ int khg_ctx_get_timings(khg_ctx *ctx, char *names, int64_t names_cap, float *ms,
 /* Which arithmetic K1 (khg_loglikes*) runs in.  All forms evaluate decodable-am-diag-gmm.cc:55-61 to fp32 accuracy
  * (|error| <= 1e-5 + 1e-6 B against an fp64 evaluation, B = |gconst| + sum |M x| + sum |V x^2| / 2; the reference's own
  * Eigen gemv fixes no summation order either):
- *   KHG_K1_F16X2     (what AUTO selects) both operands rescaled per contraction index by an exact power of two and written
- *                    as v1 + v2 2^-11 with two fp16 pieces (the representation error is 2^-24 |v|, fp32's own rounding); the
- *                    three partial products w1 x1, w1 x2, w2 x1 on v_mfma_f32_32x32x16_f16 with fp32 accumulators: measured
- *                    error BELOW the fp32 chain's (profiles/r2_probe_f16x2.txt).  Used while max |gconst| + sum_k max |w_k|
- *                    max |x_k| <= 2^28 (exact maxima of the model and the utterance set; ~1e3 for ordinary models); beyond
- *                    that khg_loglikes runs KHG_K1_FP32_PDF / _UTT by itself;
+ *   KHG_K1_F16X2S    (what AUTO selects; csrc/khg_k1_f16x2s.hip.inc) both operands rescaled per contraction index by an exact
+ *                    power of two (feature columns and the largest weight column peak in [2^14, 2^15)) and split into two fp16
+ *                    pieces v1 + v2, v1 = fp16(v), v2 = fp16(v - v1): 11 + 11 significant bits, |v - (v1 + v2)| <=
+ *                    max(2^-23 |v|, 2^-25) in scaled units; the three partial products w1 x1, w1 x2, w2 x1 on
+ *                    v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator (the dropped w2 x2 is <= 2^-22 of the term: worst case
+ *                    2^-21 per term plus an absolute floor, measured 2.1e-7 B against fp64).  Used while the split forms'
+ *                    common domain holds (max |gconst| + sum_k max |w_k| max |x_k| <= 2^28) and the floor, summed at the column
+ *                    maxima, stays <= 2e-6; otherwise khg_loglikes runs KHG_K1_F16X2, then KHG_K1_FP32_PDF / _UTT, by itself;
+ *   KHG_K1_F16X2     the same three products with the residual pieces pre-scaled by 2^11 (v = v1 + v2 2^-11: no subnormal
+ *                    residuals, |v - (v1 + v2 2^-11)| <= 2^-23 |v|) and two accumulators (main + cross, combined by one fma per
+ *                    Gaussian): worst case 2^-21 per term, measured error BELOW the fp32 chain's (profiles/r2_probe_f16x2.txt);
+ *                    same common domain;
  *   KHG_K1_BF16X3    both operands split exactly into three bf16 pieces, the six partial products of weight >= 2^-16 on
  *                    v_mfma_f32_32x32x16_bf16 with fp32 accumulation (profiles/r2_probe_bf16x3.txt); same domain rule;
  *   KHG_K1_FP32_PDF / KHG_K1_FP32_UTT   fp32 MFMA (v_mfma_f32_16x16x4_f32), pdf-major / utterance-major tiling: bit for bit the
  *                    per-Gaussian chain s = gconst; s = fmaf(M[d], x[d], s) ...; s = fmaf(-V[d]/2, x[d]^2, s) ... in k order.
- * The environment variable KHG_K1 = f16x2 | bf16x3 | pdf | utt overrides the setting (A/B runs). */
+ * The environment variable KHG_K1 = f16x2s | f16x2 | bf16x3 | pdf | utt seeds the setting at khg_ctx_create (A/B runs). */
 #define KHG_K1_AUTO 0
 #define KHG_K1_BF16X3 1
 #define KHG_K1_FP32_PDF 2
 #define KHG_K1_FP32_UTT 3
 #define KHG_K1_F16X2 4
 #define KHG_K1_F16X2S 5
-int khg_ctx_set_k1_form(khg_ctx *ctx, int form);
+int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx, KHG_OPT_K1_FORM, form) */
+
+/* Every switch of the library that is not an argument of an entry point: kernel forms and experiment knobs (what the reference
+ * has no counterpart for -- its kernels are Eigen expressions).  Values are validated (KHG_E_ARG).  An option takes effect at the
+ * next call that plans or launches the kernel it names; plans already built for an utterance set (chunk order, K1P slices) are
+ * kept.  The environment variables in brackets only seed the defaults, once, at khg_ctx_create (A/B runs of an unmodified caller). */
+#define KHG_OPT_K1_FORM 0        /* KHG_K1_* above                                                              [KHG_K1=f16x2s|f16x2|bf16x3|pdf|utt] */
+#define KHG_OPT_K1_ORDER 1       /* launch order of K1 workgroups: 0 frame tiles x pdfs descending, 1 utterance order, 2 ascending,
+                                    3 frame tiles descending                                                    [KHG_K1_ORDER=desc|none|asc|tiles] */
+#define KHG_OPT_K1_NF 2          /* fp32 utterance-major K1: 16-frame tiles per wave at D <= 40 (0 = 6, or 5)     [KHG_K1_NF] */
+#define KHG_OPT_K1P_TS 3         /* fp32 pdf-major K1: tiles per workgroup slice (default 1024)                  [KHG_K1P_TS] */
+#define KHG_OPT_K1_INTERLEAVE 4  /* fp32 utterance-major K1: frame tiles dealt round-robin (-1 auto, 0, 1)        [KHG_K1_INTERLEAVE] */
+#define KHG_OPT_K1_DBG 5         /* experiment bit mask of the tile-major split forms (results may be WRONG)      [KHG_K1B_DBG] */
+#define KHG_OPT_K2_INORDER 6     /* 1: K2 workgroups in utterance order instead of longest first                  [KHG_K2_INORDER] */
+#define KHG_OPT_K2_KS 7          /* states per thread on K2's register-resident path: 0 auto, 2, 4                [KHG_K2_KS] */
+#define KHG_OPT_K2_SERIAL 8      /* 1: the one-lane order-faithful decoder also where the wave form applies       [KHG_K2_SERIAL] */
+#define KHG_OPT_K2_PROF 9        /* 1: per-utterance cycle stamps of K2 to stderr                                 [KHG_K2_PROF] */
+#define KHG_OPT_K3_BUCKET 10     /* frames by pdf: 0 stable radix sort (reproducible sums), 1 atomic cursor scatter [KHG_K3_BUCKET=sort|atomic] */
+#define KHG_OPT_K3_FORM 11       /* 0 auto, 1 the chunk-per-block MFMA form for every shape, 2 the VALU form      [KHG_K3_FORM=block, KHG_K3_VALU=1] */
+#define KHG_OPT_K3_PHASE_B 12    /* gamma . x: 0 on the fp64 matrix pipe (exact products), 1 fp32 pipe, 256-frame fp32 partial sums [KHG_K3_PHASEB=f32] */
+#define KHG_OPT_K3_NY 13         /* workgroups per pdf in K3 (0 auto)                                             [KHG_K3_NY] */
+#define KHG_OPT_DEBUG 14         /* 1: planning statistics to stderr                                              [KHG_DEBUG] */
+#define KHG_OPT_COUNT 15
+int khg_ctx_set_option(khg_ctx *ctx, int option, int value);
+int khg_ctx_get_option(const khg_ctx *ctx, int option, int *value);
 
 /* ---- acoustic model ------------------------------------------------------------------- */
 /* AmDiagGmm (csrc/am-diag-gmm.h:96) as flat ragged arrays: pdf p owns Gaussians
@@ -281,10 +311,11 @@ int khg_model_mle_update(khg_ctx *ctx, khg_model *m, const khg_accs *a, const kh
 /* Mixing up on the handle: AmDiagGmm::SplitByCount's per-pdf DiagGmm::Split (csrc/am-diag-gmm.cc:72-90, csrc/diag-gmm.cc:780-851)
  * to targets_h[p] >= current components (the caller computes them with GetSplitTargets, csrc/model-common.cc:29-70, from
  * the per-pdf occupancies -- khg_accs_download_range(0, sumG)).  The reference draws the perturbations from the process-global
- * rand(); here they are INJECTED: randn_h holds (sum of new components) x dim standard normal deviates, consumed pdf by pdf
- * in split order, so every rank of a multi-GPU job (and the host form) perturbs identically.  Parameters bit-identical to
+ * rand(); here they are INJECTED: randn_h holds n_randn >= (sum of new components) x dim standard normal deviates, consumed pdf
+ * by pdf in split order (KHG_E_ARG when there are fewer), so every rank of a multi-GPU job (and the host form) perturbs identically.  Parameters bit-identical to
  * the host form, gconsts through logf.  The handle is updated in place (call khg_accs_relayout afterwards). */
-int khg_model_split(khg_ctx *ctx, khg_model *m, const int32_t *targets_h, float perturb_factor, const float *randn_h);
+int khg_model_split(khg_ctx *ctx, khg_model *m, const int32_t *targets_h, float perturb_factor, const float *randn_h,
+                    int64_t n_randn);
 /* total Gaussians and (gauss_off_h may be NULL) the current gauss_off[num_pdfs+1] of the handle */
 int khg_model_num_gauss(const khg_model *m, int64_t *total, int32_t *gauss_off_h);
 /* parameters back to the host (AmDiagGmm::Write needs them); any pointer may be NULL */

@@ -77,6 +77,8 @@ SIGNATURES = {
     "khg_ctx_sync": (C.c_int, [vp]),
     "khg_ctx_set_timing": (C.c_int, [vp, C.c_int]),
     "khg_ctx_set_k1_form": (C.c_int, [vp, C.c_int]),
+    "khg_ctx_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
+    "khg_ctx_get_option": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "khg_ctx_get_timings": (C.c_int, [vp, C.c_char_p, C.c_int64, c_f32p, C.c_int32, c_i32p]),
     "khg_model_create": (C.c_int, [vp, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, c_f32p, C.POINTER(vp)]),
     "khg_model_destroy": (C.c_int, [vp]),
@@ -127,7 +129,7 @@ SIGNATURES = {
     "khg_diag_gmm_merge": (C.c_int, [c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p]),
     "khg_model_set_weights": (C.c_int, [vp, vp, c_f32p]),
     "khg_model_mle_update": (C.c_int, [vp, vp, vp, C.POINTER(MleOptionsC), C.c_uint16, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p]),
-    "khg_model_split": (C.c_int, [vp, vp, c_i32p, C.c_float, c_f32p]),
+    "khg_model_split": (C.c_int, [vp, vp, c_i32p, C.c_float, c_f32p, C.c_int64]),
     "khg_model_num_gauss": (C.c_int, [vp, C.POINTER(C.c_int64), c_i32p]),
     "khg_model_download": (C.c_int, [vp, vp, c_f32p, c_f32p, c_f32p, c_f32p]),
     "khg_accs_relayout": (C.c_int, [vp, vp, vp]),

@@ -54,7 +54,7 @@ struct khg_ctx {
   float* dump_d = nullptr;          // 256 floats nobody reads (K1 f16x2s: where the pipeline's first, empty value goes)
   bool timing = false;
   std::vector<khg_timing> timings;
-  int k1_form = KHG_K1_AUTO;      // khg_ctx_set_k1_form; the KHG_K1 environment variable overrides it
+  int opt[KHG_OPT_COUNT] = {};    // khg_ctx_set_option (KHG_OPT_*); the environment variables of include/khg_hip.h only seed the defaults, once, at khg_ctx_create
 };
 // scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled)
 struct KernelTimer {
@@ -85,6 +85,7 @@ static int dev_upload(khg_ctx* ctx, T** p, const std::vector<T>& v) {
 }
 #define DEVFREE(p) do { if (p) { (void)hipFree((void*)(p)); (p) = nullptr; } } while (0)
 
+static void ctx_defaults_from_env(khg_ctx* c);
 extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
   if (!out) return khg_set_error(KHG_E_ARG, "khg_ctx_create: out is NULL");
   int n = 0;
@@ -102,6 +103,7 @@ extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
   else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   for (auto& s : c->sides) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  ctx_defaults_from_env(c);
   int rc = dev_alloc(&c->err_flag_d, 1);
   if (!rc) rc = dev_alloc(&c->dump_d, 256);
   if (rc) { delete c; return rc; }
@@ -143,10 +145,52 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
   *n_out = n;
   return KHG_OK;
 }
-extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) {
-  if (!c || form < KHG_K1_AUTO || form > KHG_K1_F16X2S) return khg_set_error(KHG_E_ARG, "khg_ctx_set_k1_form: bad arguments");
-  c->k1_form = form;
+// valid range of every option (inclusive)
+static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 1}, {0, 2}, {0, 1}, {0, 64}, {0, 1}};
+extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
+  if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
+  if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
+    return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: option " + std::to_string(opt) + " takes values " + std::to_string(k_opt_range[opt].lo) + " .. " + std::to_string(k_opt_range[opt].hi));
+  c->opt[opt] = value;
   return KHG_OK;
+}
+extern "C" int khg_ctx_get_option(const khg_ctx* c, int opt, int* value) {
+  if (!c || !value || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_get_option: bad arguments");
+  *value = c->opt[opt];
+  return KHG_OK;
+}
+extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) { return khg_ctx_set_option(c, KHG_OPT_K1_FORM, form); }
+// Defaults from the environment, read ONCE per context (A/B runs of an unmodified caller): NAME=value, value an integer or one of the words
+// listed.  Everything else goes through khg_ctx_set_option.
+static void ctx_defaults_from_env(khg_ctx* c) {
+  static const struct { const char* name; int opt; const char* words; } tab[] = {
+    {"KHG_K1", KHG_OPT_K1_FORM, "auto=0,bf16x3=1,pdf=2,fp32=2,utt=3,f16x2=4,f16x2s=5"},
+    {"KHG_K1_ORDER", KHG_OPT_K1_ORDER, "desc=0,none=1,asc=2,tiles=3"},
+    {"KHG_K1_NF", KHG_OPT_K1_NF, ""}, {"KHG_K1P_TS", KHG_OPT_K1P_TS, ""}, {"KHG_K1_INTERLEAVE", KHG_OPT_K1_INTERLEAVE, ""},
+    {"KHG_K1B_DBG", KHG_OPT_K1_DBG, ""}, {"KHG_K2_INORDER", KHG_OPT_K2_INORDER, ""}, {"KHG_K2_KS", KHG_OPT_K2_KS, ""},
+    {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},
+    {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
+    {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1"},
+    {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}};
+  c->opt[KHG_OPT_K1_INTERLEAVE] = -1;
+  c->opt[KHG_OPT_K1P_TS] = 1024;
+  for (const auto& t : tab) {
+    const char* e = getenv(t.name);
+    if (!e || !*e) continue;
+    int v = atoi(e);
+    bool word = false;
+    for (const char* w = t.words; *w;) {                 // "word=value,word=value"
+      const char* eq = strchr(w, '=');
+      const size_t n = (size_t)(eq - w);
+      if (strlen(e) == n && strncmp(e, w, n) == 0) { v = atoi(eq + 1); word = true; break; }
+      const char* comma = strchr(eq, ',');
+      if (!comma) break;
+      w = comma + 1;
+    }
+    if (!word && *t.words && !(e[0] >= '0' && e[0] <= '9') && e[0] != '-') continue;      // an unknown word: ignored
+    if (v >= k_opt_range[t.opt].lo && v <= k_opt_range[t.opt].hi) c->opt[t.opt] = v;
+  }
 }
 static int check_err_flag(khg_ctx* c, const char* where);
 extern "C" int khg_ctx_sync(khg_ctx* c) {
@@ -679,7 +723,7 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
   else hipLaunchKernelGGL((k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
 }
 // 16-frame tiles per wave: 6 x 20 B-operand VGPRs fit 2 waves/SIMD at D <= 40 (KHG_K1_NF=5 selects the smaller chunk)
-static int k1_nf(int KQ) { const char* e = getenv("KHG_K1_NF"); return KQ != 10 ? 5 : (e && atoi(e) == 5) ? 5 : 6; }
+static int k1_nf(const khg_ctx* ctx, int KQ) { return KQ != 10 ? 5 : ctx->opt[KHG_OPT_K1_NF] == 5 ? 5 : 6; }
 
 // K1 in pdf-major form: plan (entries grouped by pdf, cut into workgroup slices) + repacked features.
 static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
@@ -727,7 +771,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
       }
     }
     // slices: <= TS tiles and <= K1P_MAXENT entries of one pdf each
-    const int TS = getenv("KHG_K1P_TS") ? atoi(getenv("KHG_K1P_TS")) : 1024;
+    const int TS = std::max(1, ctx->opt[KHG_OPT_K1P_TS]);
     std::vector<K1pSlice> slices;
     for (int p = 0; p < m->P; ++p) {
       int64_t e = cnt[(size_t)p];
@@ -762,7 +806,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     u->p_nslices = (int32_t)slices.size();
-    if (getenv("KHG_DEBUG")) { long long tt = 0; for (auto& s : slices) tt += s.ntiles; fprintf(stderr, "[khg] pdf-major plan: %zu entries, %zu slices, %lld tiles\n", ents.size(), slices.size(), tt); }
+    if (ctx->opt[KHG_OPT_DEBUG]) { long long tt = 0; for (auto& s : slices) tt += s.ntiles; fprintf(stderr, "[khg] pdf-major plan: %zu entries, %zu slices, %lld tiles\n", ents.size(), slices.size(), tt); }
     u->p_reach = (int)reachable_only;
     u->p_P = m->P;
     u->p_goff = m->gauss_off;
@@ -845,7 +889,7 @@ static int ensure_x32_layout(khg_ctx* ctx, khg_utts* u) {
 // drains are then the short ones (a launch of 12 500 utterances -- the 8-GPU shard -- is ~49 rounds of workgroups whose durations
 // differ 4x).  K1bChunk and K1sChunk have the same layout.
 template <class Chunk>
-static void plan_x32_chunks(const khg_utts* u, int per, std::vector<Chunk>* ch) {
+static void plan_x32_chunks(const khg_utts* u, int per, int order, std::vector<Chunk>* ch) {
   ch->clear();
   for (int i = 0; i < u->n_utt; ++i) {
     const int n32 = (int)((u->frame_off[i + 1] - u->frame_off[i] + 31) / 32);
@@ -856,10 +900,10 @@ static void plan_x32_chunks(const khg_utts* u, int per, std::vector<Chunk>* ch) 
       if (t1 > t0) ch->push_back(Chunk{i, t0, t1 - t0, 0});
     }
   }
-  const char* oe = getenv("KHG_K1_ORDER");     // experiments: none | asc | tiles (default: frame tiles x pdfs, descending)
-  auto cost = [&](const Chunk& c) { return (int64_t)c.ntiles * ((oe && strcmp(oe, "tiles") == 0) ? 1 : (u->pdf_off[c.utt + 1] - u->pdf_off[c.utt])); };
-  if (oe && strcmp(oe, "asc") == 0) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) < cost(b); });
-  else if (!(oe && strcmp(oe, "none") == 0)) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) > cost(b); });
+  // KHG_OPT_K1_ORDER (experiments): 0 frame tiles x pdfs descending (default), 1 utterance order, 2 ascending, 3 frame tiles descending
+  auto cost = [&](const Chunk& c) { return (int64_t)c.ntiles * (order == 3 ? 1 : (u->pdf_off[c.utt + 1] - u->pdf_off[c.utt])); };
+  if (order == 2) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) < cost(b); });
+  else if (order != 1) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) > cost(b); });
 }
 static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
   int rc = ensure_x32_layout(ctx, u);
@@ -867,7 +911,7 @@ static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
   if (u->bchunks_d && u->bchunk_nt == NTMAX) return KHG_OK;
   DEVFREE(u->bchunks_d);
   std::vector<K1bChunk> ch;
-  plan_x32_chunks(u, 8 * NTMAX, &ch);
+  plan_x32_chunks(u, 8 * NTMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
   rc = dev_upload(ctx, &u->bchunks_d, ch);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -888,10 +932,14 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool 
       if (rc) return rc;
       m->wimgb_tiles = m->ntiles;
     }
+    rc = m->wimgb_sync.before_pack(ctx->stream);
+    if (rc) return rc;
     KernelTimer kt(ctx, "k0b_pack_tiles");
     if (KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
     else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
     HIPCHK(hipGetLastError());
+    rc = m->wimgb_sync.after_pack(ctx->stream);
+    if (rc) return rc;
     m->wimgb_valid = true;
   }
   if (!u->xb3_d || u->xb3_ks != KS) {
@@ -914,15 +962,21 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool 
   a.xb = u->xb3_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->bchunks_d;
   a.wimg = m->wimgb_d; a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
-  a.dbg = getenv("KHG_K1B_DBG") ? atoi(getenv("KHG_K1B_DBG")) : 0;
+  a.dbg = ctx->opt[KHG_OPT_K1_DBG];
   if (u->n_bchunks > 0) {
     const size_t lds = (size_t)k1b_ring(KS) * k1b_group(KS) * k1b_tile_bytes(KS);
     const void* fn = KS == 5 ? (const void*)k1b_loglikes<5, 2> : (const void*)k1b_loglikes<10, 1>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    KernelTimer kt(ctx, "k1_loglikes");
-    if (KS == 5) hipLaunchKernelGGL((k1b_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    rc = m->wimgb_sync.before_read(ctx->stream);
+    if (rc) return rc;
+    {
+      KernelTimer kt(ctx, "k1_loglikes");
+      if (KS == 5) hipLaunchKernelGGL((k1b_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+      else hipLaunchKernelGGL((k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    }
     HIPCHK(hipGetLastError());
+    rc = m->wimgb_sync.after_read(ctx->stream);
+    if (rc) return rc;
   }
   u->ll_valid = true;
   return KHG_OK;
@@ -1044,10 +1098,14 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
       if (rc) return rc;
       m->wimgh_tiles = m->ntiles;
     }
+    rc = m->wimgh_sync.before_pack(ctx->stream);
+    if (rc) return rc;
     KernelTimer kt(ctx, "k0h_pack_tiles");
     if (KS == 5) hipLaunchKernelGGL(k0h_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
     else hipLaunchKernelGGL(k0h_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
     HIPCHK(hipGetLastError());
+    rc = m->wimgh_sync.after_pack(ctx->stream);
+    if (rc) return rc;
     m->wimgh_ex = u->xh_ex;
   }
   rc = ensure_walk(ctx, m, u, reachable_only);
@@ -1056,7 +1114,7 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
   a.xh = u->xh_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->bchunks_d;
   a.wimg = m->wimgh_d; a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
-  a.dbg = getenv("KHG_K1B_DBG") ? atoi(getenv("KHG_K1B_DBG")) : 0;
+  a.dbg = ctx->opt[KHG_OPT_K1_DBG];
   a.tbuf = nullptr;
 #ifdef K1H_TIMING
   uint64_t* tbuf_d = nullptr;
@@ -1071,10 +1129,16 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
     const size_t lds = (size_t)k1h_lds_bytes(KS);
     const void* fn = KS == 5 ? (const void*)k1h_loglikes<5, 2> : (const void*)k1h_loglikes<10, K1H_NT10>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    KernelTimer kt(ctx, "k1_loglikes");
-    if (KS == 5) hipLaunchKernelGGL((k1h_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k1h_loglikes<10, K1H_NT10>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    rc = m->wimgh_sync.before_read(ctx->stream);
+    if (rc) return rc;
+    {
+      KernelTimer kt(ctx, "k1_loglikes");
+      if (KS == 5) hipLaunchKernelGGL((k1h_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+      else hipLaunchKernelGGL((k1h_loglikes<10, K1H_NT10>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+    }
     HIPCHK(hipGetLastError());
+    rc = m->wimgh_sync.after_read(ctx->stream);
+    if (rc) return rc;
   }
 #ifdef K1H_TIMING
   if (tbuf_d) {      // measurement build only: per-wave cycle breakdown, averaged by the number of frame tiles the wave owns
@@ -1126,7 +1190,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
   if (!u->schunks_d || u->schunk_nmax != NMAX) {
     DEVFREE(u->schunks_d);
     std::vector<K1sChunk> ch;
-    plan_x32_chunks(u, NMAX, &ch);
+    plan_x32_chunks(u, NMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
     rc = dev_upload(ctx, &u->schunks_d, ch);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1210,7 +1274,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
   if (u->n_schunks > 0) {
     rc = m->wimgs_sync.before_read(ctx->stream);
     if (rc) return rc;
-    const size_t lds = (size_t)NMAX * k1s_xtile_bytes(KS);
+    const size_t lds = (size_t)NMAX * k1s_xtile_bytes(KS) + 64;     // + the work-item counter
     const void* fn = KS == 5 ? (const void*)k1s_loglikes<5> : (const void*)k1s_loglikes<10>;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
@@ -1244,14 +1308,7 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
   {
     // which K1: bf16x3 (default: the bf16 matrix cores at fp32 accuracy), or one of the fp32-MFMA forms -- pdf-major (pdfs of
     // <= 128 Gaussians) / utterance-major -- whose per-Gaussian fmaf chain is pinned bit for bit by the tests
-    int form = ctx->k1_form;
-    if (const char* env = getenv("KHG_K1")) {
-      if (strcmp(env, "bf16x3") == 0) form = KHG_K1_BF16X3;
-      else if (strcmp(env, "f16x2") == 0) form = KHG_K1_F16X2;
-      else if (strcmp(env, "f16x2s") == 0) form = KHG_K1_F16X2S;
-      else if (strcmp(env, "pdf") == 0 || strcmp(env, "fp32") == 0) form = KHG_K1_FP32_PDF;
-      else if (strcmp(env, "utt") == 0) form = KHG_K1_FP32_UTT;
-    }
+    int form = ctx->opt[KHG_OPT_K1_FORM];
     if (form == KHG_K1_AUTO) form = KHG_K1_F16X2S;
     if (u->N == 0 || u->pdfs.empty()) { u->ll_valid = true; return KHG_OK; }
     if (form == KHG_K1_F16X2S) {
@@ -1275,9 +1332,9 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     if (form == KHG_K1_FP32_PDF && maxG <= 128) return loglikes_pdf_major(ctx, m, u, reachable_only);
   }
-  if (!u->chunks_d || u->chunk_kq != m->KQ * 16 + k1_nf(m->KQ)) {
+  if (!u->chunks_d || u->chunk_kq != m->KQ * 16 + k1_nf(ctx, m->KQ)) {
     DEVFREE(u->chunks_d);
-    const int maxtiles = 4 * k1_nf(m->KQ);
+    const int maxtiles = 4 * k1_nf(ctx, m->KQ);
     std::vector<K1Chunk> ch;
     for (int i = 0; i < u->n_utt; ++i) {
       int64_t T = u->frame_off[i + 1] - u->frame_off[i];
@@ -1293,7 +1350,7 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
       }
     }
     u->n_chunks = (int)ch.size();
-    u->chunk_kq = m->KQ * 16 + k1_nf(m->KQ);
+    u->chunk_kq = m->KQ * 16 + k1_nf(ctx, m->KQ);
     rc = dev_upload(ctx, &u->chunks_d, ch);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
@@ -1305,11 +1362,11 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
   a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
   a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d; a.D = m->D;
   a.interleave = reachable_only ? 1 : 0;
-  if (const char* e = getenv("KHG_K1_INTERLEAVE")) a.interleave = atoi(e);
+  if (ctx->opt[KHG_OPT_K1_INTERLEAVE] >= 0) a.interleave = ctx->opt[KHG_OPT_K1_INTERLEAVE];
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
-    if (m->KQ == 10 && k1_nf(10) == 6) launch_k1<10, 6, 2>(a, u->n_chunks, aligned, ctx->stream);
+    if (m->KQ == 10 && k1_nf(ctx, 10) == 6) launch_k1<10, 6, 2>(a, u->n_chunks, aligned, ctx->stream);
     else if (m->KQ == 10) launch_k1<10, 5, 2>(a, u->n_chunks, aligned, ctx->stream);
     else launch_k1<20, 5, 1>(a, u->n_chunks, aligned, ctx->stream);
     HIPCHK(hipGetLastError());
@@ -1418,8 +1475,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     if (rc2) return rc2;
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  a.order = getenv("KHG_K2_INORDER") ? nullptr : u->k2_order_d;
-  const bool k2prof = getenv("KHG_K2_PROF") != nullptr;
+  a.order = ctx->opt[KHG_OPT_K2_INORDER] ? nullptr : u->k2_order_d;
+  const bool k2prof = ctx->opt[KHG_OPT_K2_PROF] != 0;
   if (k2prof) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&a.prof), sizeof(long long) * 8 * (size_t)u->n_utt)); HIPCHK(hipMemset(a.prof, 0, sizeof(long long) * 8 * (size_t)u->n_utt)); }
   a.beam = cfg->beam; a.retry_beam = cfg->retry_beam; a.acoustic_scale = cfg->acoustic_scale;
   a.beam_delta = cfg->beam_delta; a.hash_ratio = cfg->hash_ratio;
@@ -1430,8 +1487,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   for (int i = 0; i < u->n_utt; ++i) max_npdf = std::max<size_t>(max_npdf, (size_t)(u->pdf_off[i + 1] - u->pdf_off[i]));
   // threads: one destination state each (up to 1024), KS states per thread beyond that
   int nthr = (int)std::min<size_t>(1024, (S + 63) / 64 * 64);
-  int ks_force = 0;
-  if (const char* e = getenv("KHG_K2_KS")) ks_force = atoi(e);   // experiment: states per thread on the register-resident path
+  const int ks_force = ctx->opt[KHG_OPT_K2_KS];   // experiment: states per thread on the register-resident path
   if (ks_force == 2 || ks_force == 4) nthr = (int)std::min<size_t>(1024, ((S + ks_force - 1) / ks_force + 63) / 64 * 64);
   const size_t nwave = nthr / 64;
   // register-resident path for the whole batch: in-degree <= 3 (up to 4 states per thread) or <= 6 (one state per thread)
@@ -1488,7 +1544,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     // the one-lane form handles everything else
     const int odeg = std::max(1, (int)u->max_outdeg);
     const size_t lds_w = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 8 * (S + 1) + 5 * 4 * A + 8 * ((S * odeg + 63) / 64 + 2) + A + 64;
-    const bool wave_ok = !gmem && !u->has_eps && S <= 1000 && odeg <= 8 && lds_w <= 160 * 1024 && getenv("KHG_K2_SERIAL") == nullptr;
+    const bool wave_ok = !gmem && !u->has_eps && S <= 1000 && odeg <= 8 && lds_w <= 160 * 1024 && !ctx->opt[KHG_OPT_K2_SERIAL];
     if (wave_ok) {
       if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
       hipLaunchKernelGGL(k2_viterbi_faithful_wave, dim3(u->n_utt), dim3(64), lds_w, side, a, odeg);
@@ -1640,8 +1696,8 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
     {
       KernelTimer kt(ctx, "k3_bucket");
-      const char* bk = getenv("KHG_K3_BUCKET");      // "atomic": cursor-bump scatter (bucket order depends on the atomics)
-      if ((bk && strcmp(bk, "atomic") == 0) || u->N >= (int64_t)INT_MAX) {
+      // KHG_OPT_K3_BUCKET = 1: cursor-bump scatter (bucket order depends on the atomics)
+      if (ctx->opt[KHG_OPT_K3_BUCKET] == 1 || u->N >= (int64_t)INT_MAX) {
         hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
@@ -1673,9 +1729,9 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
-    const bool use_mfma = maxG <= 128 && getenv("KHG_K3_VALU") == nullptr;
-    const char* k3form = getenv("KHG_K3_FORM");     // "block": the chunk-per-block MFMA form for every shape
-    const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && !(k3form && strcmp(k3form, "block") == 0);
+    const int k3form = ctx->opt[KHG_OPT_K3_FORM];     // 1: the chunk-per-block MFMA form for every shape; 2: the VALU form
+    const bool use_mfma = maxG <= 128 && k3form != 2;
+    const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && k3form != 1;
     if (use_wave) {
       // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
       const int nb = (maxG + 15) / 16;
@@ -1683,7 +1739,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
                                           sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
       const int64_t avg_tiles = (u->N / std::max(1, m->P) + 15) / 16;
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, (avg_tiles + 15) / 16), (4096 + m->P - 1) / m->P));
-      if (const char* e = getenv("KHG_K3_NY")) ny = std::max(1, atoi(e));
+      if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
       // per-pdf log-like partials (always) and, with several blocks per pdf, the slice images they park
       const size_t nsum1 = (size_t)nb * 16 * 80 + (size_t)nb * 16 + 1;
       if (u->k3_llpart_n < (size_t)m->P) {
@@ -1704,12 +1760,13 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       KernelTimer kt(ctx, "k3_accumulate");
       // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
       // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
-      const char* pb = getenv("KHG_K3_PHASEB");
-      const bool exact_b = !(pb && strcmp(pb, "f32") == 0);
+      const bool exact_b = ctx->opt[KHG_OPT_K3_PHASE_B] == 0;
       // k3_accumulate_wave32: the workgroup's fp64 image + W + two x planes per wave
       const size_t lds32 = sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16) + sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 2 * 16 * 20);
 #define K3_WAVE_LAUNCH(NBV)                                                                                            \
   do {                                                                                                                  \
+    if (!exact_b && lds32 > 48 * 1024)                                                                                  \
+      HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
     if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);          \
     else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(m->P, ny), dim3(256), lds32, ctx->stream, a);              \
     if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny);               \
@@ -1728,7 +1785,7 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
       // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
-      if (const char* e = getenv("KHG_K3_NY")) ny = std::max(1, atoi(e));
+      if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
       KernelTimer kt(ctx, "k3_accumulate");
       if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
       else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
@@ -1973,7 +2030,7 @@ extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* 
   return KHG_OK;
 }
 
-extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* targets, float perturb, const float* randn) {
+extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* targets, float perturb, const float* randn, int64_t n_randn) {
   if (!ctx || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_split: bad arguments");
   if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_split: the model has no weights (khg_model_set_weights)");
   const int P = m->P, D = m->D;
@@ -1981,6 +2038,7 @@ extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* target
   std::vector<int64_t> rand_off((size_t)P + 1, 0);
   for (int p = 0; p < P; ++p) {
     const int cur = m->gauss_off[p + 1] - m->gauss_off[p];
+    if (cur == 0 && targets[p] > 0) return khg_set_error(KHG_E_RUNTIME, "khg_model_split: pdf " + std::to_string(p) + " has no component to split");
     if (targets[p] < cur)   // csrc/diag-gmm.cc:782-786
       return khg_set_error(KHG_E_RUNTIME, "Cannot split from " + std::to_string(cur) + " to " + std::to_string(targets[p]) + " components");
     new_off[(size_t)p + 1] = new_off[(size_t)p] + targets[p];
@@ -1989,6 +2047,8 @@ extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* target
   const int64_t nnew = rand_off[(size_t)P], out = new_off[(size_t)P];
   if (nnew == 0) return KHG_OK;
   if (!randn) return khg_set_error(KHG_E_ARG, "khg_model_split: randn_h is NULL");
+  if (n_randn < nnew * D)
+    return khg_set_error(KHG_E_ARG, "khg_model_split: randn_h holds " + std::to_string(n_randn) + " deviates, " + std::to_string(nnew * D) + " are needed (new components x dim)");
   std::vector<float> rv(randn, randn + (size_t)nnew * D);
   int32_t *new_off_d = nullptr, *bad_d = nullptr;
   int64_t* rand_off_d = nullptr;

@@ -36,6 +36,14 @@ void Check(int rc) {
   throw std::runtime_error(msg ? msg : "khg error");
 }
 
+// The C-ABI calls that launch kernels, wait for the stream or copy between host and device run WITHOUT the GIL (two contexts on
+// two streams driven from two Python threads is a supported mode); Check() needs it back: it may raise.
+template <class F>
+int NoGil(F&& f) {
+  py::gil_scoped_release release;
+  return f();
+}
+
 template <class T>
 using Arr = py::array_t<T, py::array::c_style | py::array::forcecast>;
 
@@ -55,12 +63,29 @@ struct KContext {
   }
   ~KContext() { close(); }
   void close() { if (h) { khg_ctx_destroy(h); h = nullptr; } }
-  void sync() { Check(khg_ctx_sync(h)); }
+  void sync() { Check(NoGil([&] { return khg_ctx_sync(h); })); }
   void set_timing(bool on) { Check(khg_ctx_set_timing(h, on ? 1 : 0)); }
   void set_k1_form(const std::string& f) {
     int v = f == "auto" ? KHG_K1_AUTO : f == "bf16x3" ? KHG_K1_BF16X3 : (f == "pdf" || f == "fp32") ? KHG_K1_FP32_PDF : f == "utt" ? KHG_K1_FP32_UTT : f == "f16x2" ? KHG_K1_F16X2 : f == "f16x2s" ? KHG_K1_F16X2S : -1;
     if (v < 0) throw py::key_error(f);
     Check(khg_ctx_set_k1_form(h, v));
+  }
+  // khg_ctx_set_option by name ("k3_form", ...) or by number; -> the previous value
+  static int opt_id(const py::object& o) {
+    if (py::isinstance<py::int_>(o)) return o.cast<int>();
+    static const char* names[KHG_OPT_COUNT] = {"k1_form", "k1_order", "k1_nf", "k1p_ts", "k1_interleave", "k1_dbg", "k2_inorder", "k2_ks", "k2_serial",
+                                               "k2_prof", "k3_bucket", "k3_form", "k3_phase_b", "k3_ny", "debug"};
+    const std::string n = o.cast<std::string>();
+    for (int i = 0; i < KHG_OPT_COUNT; ++i) if (n == names[i]) return i;
+    throw py::key_error(n);
+  }
+  int get_option(py::object name) { int v = 0; Check(khg_ctx_get_option(h, opt_id(name), &v)); return v; }
+  int set_option(py::object name, int value) {
+    const int id = opt_id(name);
+    int old = 0;
+    Check(khg_ctx_get_option(h, id, &old));
+    Check(khg_ctx_set_option(h, id, value));
+    return old;
   }
   py::list timings() {
     const int cap = 4096;
@@ -129,8 +154,9 @@ struct KModel {
     if (targets.shape(0) != num_pdfs) throw py::value_error("split: one target per pdf");
     Arr<float> r;
     const float* rp = nullptr;
-    if (!randn.is_none()) { r = randn.cast<Arr<float>>(); rp = r.data(); }
-    Check(khg_model_split(ctx->h, h, targets.data(), perturb, rp));
+    int64_t nr = 0;
+    if (!randn.is_none()) { r = randn.cast<Arr<float>>(); rp = r.data(); nr = (int64_t)r.size(); }
+    Check(NoGil([&] { return khg_model_split(ctx->h, h, targets.data(), perturb, rp, nr); }));
     Arr<int32_t> go({(py::ssize_t)num_pdfs + 1});
     Check(khg_model_num_gauss(h, nullptr, go.mutable_data()));
     gauss_off = go;
@@ -142,7 +168,7 @@ struct KModel {
     float* wp = nullptr;
     Arr<float> wa;
     if (weights) { wa = Arr<float>({G}); wp = wa.mutable_data(); w = wa; }
-    Check(khg_model_download(ctx->h, h, wp, gc.mutable_data(), miv.mutable_data(), iv.mutable_data()));
+    Check(NoGil([&] { return khg_model_download(ctx->h, h, wp, gc.mutable_data(), miv.mutable_data(), iv.mutable_data()); }));
     py::dict d;
     d["gauss_off"] = py::array(gauss_off).attr("copy")();
     d["weights"] = w; d["gconsts"] = gc; d["means_invvars"] = miv; d["inv_vars"] = iv;
@@ -186,7 +212,7 @@ struct KAccs {
   uintptr_t device_ptr() { void* p = nullptr; Check(khg_accs_device_ptr(h, &p)); return reinterpret_cast<uintptr_t>(p); }
   void allreduce(py::object comm, bool wire_fp32) {
     void* c = comm.is_none() ? nullptr : comm.cast<KComm*>()->h;
-    Check(wire_fp32 ? khg_accs_allreduce_f32(ctx->h, h, c) : khg_accs_allreduce(ctx->h, h, c));
+    Check(NoGil([&] { return wire_fp32 ? khg_accs_allreduce_f32(ctx->h, h, c) : khg_accs_allreduce(ctx->h, h, c); }));
   }
   py::dict split(Arr<double> buf) {
     const int64_t G = sumG, D = dim, nt = num_tids;
@@ -215,25 +241,25 @@ struct KAccs {
   }
   Arr<double> download_range(int64_t first, int64_t count) {
     Arr<double> out({(py::ssize_t)count});
-    Check(khg_accs_download_range(ctx->h, h, first, count, out.mutable_data()));
+    Check(NoGil([&] { return khg_accs_download_range(ctx->h, h, first, count, out.mutable_data()); }));
     return out;
   }
   py::dict download_trans() {
     Arr<double> tr({(py::ssize_t)num_tids + 1});
     double sc[8];
-    Check(khg_accs_download_trans(ctx->h, h, tr.mutable_data(), sc));
+    Check(NoGil([&] { return khg_accs_download_trans(ctx->h, h, tr.mutable_data(), sc); }));
     py::dict d;
     d["trans_acc"] = tr; d["total_frames"] = sc[0]; d["total_log_like"] = sc[1];
     return d;
   }
   py::dict download() {
     Arr<double> buf({(py::ssize_t)size});
-    Check(khg_accs_download(ctx->h, h, buf.mutable_data()));
+    Check(NoGil([&] { return khg_accs_download(ctx->h, h, buf.mutable_data()); }));
     return split(buf);
   }
   void upload(Arr<double> b) {
     if (b.size() != size) throw py::value_error("upload: wrong block size");
-    Check(khg_accs_upload(ctx->h, h, b.data()));
+    Check(NoGil([&] { return khg_accs_upload(ctx->h, h, b.data()); }));
   }
 };
 
@@ -256,7 +282,7 @@ py::dict KModel::mle_update(KAccs& accs, py::object opts, int flags) {
   }
   float oc = 0, cnt = 0;
   int32_t fe = 0, fg = 0, rm = 0;
-  Check(khg_model_mle_update(ctx->h, h, accs.h, &o, (uint16_t)(flags & 0xFFFF), &oc, &cnt, &fe, &fg, &rm));
+  Check(NoGil([&] { return khg_model_mle_update(ctx->h, h, accs.h, &o, (uint16_t)(flags & 0xFFFF), &oc, &cnt, &fe, &fg, &rm); }));
   if (rm) {
     Arr<int32_t> go({(py::ssize_t)num_pdfs + 1});
     Check(khg_model_num_gauss(h, nullptr, go.mutable_data()));
@@ -324,7 +350,7 @@ struct KUtts {
     Check(khg_utts_pdf_first(h, first.mutable_data()));
     return py::array(first)[py::slice(0, n, 1)];
   }
-  void loglikes(KModel& m, bool reachable_only) { Check(reachable_only ? khg_loglikes_reachable(ctx->h, m.h, h) : khg_loglikes(ctx->h, m.h, h)); }
+  void loglikes(KModel& m, bool reachable_only) { Check(NoGil([&] { return reachable_only ? khg_loglikes_reachable(ctx->h, m.h, h) : khg_loglikes(ctx->h, m.h, h); })); }
   py::tuple loglikes_layout() {
     Arr<int64_t> off({(py::ssize_t)n_utt + 1});
     int64_t tot = 0;
@@ -337,7 +363,7 @@ struct KUtts {
     Check(khg_loglikes_layout(h, off.mutable_data(), &tot));
     Check(khg_utts_num_pdfs(h, poff.mutable_data()));
     std::vector<float> buf((size_t)(tot > 0 ? tot : 1));
-    Check(khg_loglikes_download(ctx->h, h, buf.data()));
+    Check(NoGil([&] { return khg_loglikes_download(ctx->h, h, buf.data()); }));
     py::list out;
     for (int u = 0; u < n_utt; ++u) {
       const int64_t T = frame_off.at(u + 1) - frame_off.at(u), tpad = (T + 31) / 32 * 32, n = poff.at(u + 1) - poff.at(u);
@@ -357,7 +383,7 @@ struct KUtts {
       const int64_t T = frame_off.at(u + 1) - frame_off.at(u), tpad = (T + 31) / 32 * 32;
       for (py::ssize_t j = 0; j < m.shape(0); ++j) std::memcpy(buf.data() + off.at(u) + j * tpad, m.data() + j * m.shape(1), sizeof(float) * (size_t)T);
     }
-    Check(khg_loglikes_upload(ctx->h, h, buf.data()));
+    Check(NoGil([&] { return khg_loglikes_upload(ctx->h, h, buf.data()); }));
   }
   py::object align(KTransitions& tm, float beam, float retry_beam, float acoustic_scale, bool careful, int64_t max_active, int min_active,
                    float beam_delta, float hash_ratio, py::object download) {
@@ -368,21 +394,21 @@ struct KUtts {
     c.min_active = min_active; c.beam_delta = beam_delta; c.hash_ratio = hash_ratio;
     const bool summary = py::isinstance<py::str>(download) && download.cast<std::string>() == "summary";
     if (!summary && !download.cast<bool>()) {
-      Check(khg_align(ctx->h, tm.h, h, &c, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
+      Check(NoGil([&] { return khg_align(ctx->h, tm.h, h, &c, nullptr, nullptr, nullptr, 0, nullptr, nullptr); }));
       return py::none();
     }
     Arr<float> like({(py::ssize_t)n_utt});
     Arr<int32_t> status({(py::ssize_t)n_utt});
     py::dict d;
     if (summary) {
-      Check(khg_align(ctx->h, tm.h, h, &c, nullptr, nullptr, nullptr, 0, like.mutable_data(), status.mutable_data()));
+      Check(NoGil([&] { return khg_align(ctx->h, tm.h, h, &c, nullptr, nullptr, nullptr, 0, like.mutable_data(), status.mutable_data()); }));
       d["like"] = like; d["status"] = status;
       return d;
     }
     const int64_t N = frame_off.at(n_utt), wcap = N + 16 * (int64_t)n_utt + 1024;
     Arr<int32_t> ali({(py::ssize_t)(N > 0 ? N : 1)}), words({(py::ssize_t)wcap});
     Arr<int64_t> woff({(py::ssize_t)n_utt + 1});
-    Check(khg_align(ctx->h, tm.h, h, &c, ali.mutable_data(), words.mutable_data(), woff.mutable_data(), wcap, like.mutable_data(), status.mutable_data()));
+    Check(NoGil([&] { return khg_align(ctx->h, tm.h, h, &c, ali.mutable_data(), words.mutable_data(), woff.mutable_data(), wcap, like.mutable_data(), status.mutable_data()); }));
     d["ali"] = py::array(ali)[py::slice(0, N, 1)];
     d["like"] = like; d["status"] = status;
     d["words"] = py::array(words)[py::slice(0, woff.at(n_utt), 1)];
@@ -391,15 +417,15 @@ struct KUtts {
   }
   void upload_ali(Arr<int32_t> a) {
     if (a.shape(0) != frame_off.at(n_utt)) throw py::value_error("upload_ali: one transition-id per frame");
-    Check(khg_ali_upload(ctx->h, h, a.data()));
+    Check(NoGil([&] { return khg_ali_upload(ctx->h, h, a.data()); }));
   }
   py::object download_ali() {
     const int64_t N = frame_off.at(n_utt);
     Arr<int32_t> a({(py::ssize_t)(N > 0 ? N : 1)});
-    Check(khg_ali_download(ctx->h, h, a.mutable_data()));
+    Check(NoGil([&] { return khg_ali_download(ctx->h, h, a.mutable_data()); }));
     return py::array(a)[py::slice(0, N, 1)];
   }
-  void acc_stats(KModel& m, KTransitions& tm, KAccs& accs, float weight) { Check(khg_acc_stats(ctx->h, m.h, tm.h, h, weight, accs.h)); }
+  void acc_stats(KModel& m, KTransitions& tm, KAccs& accs, float weight) { Check(NoGil([&] { return khg_acc_stats(ctx->h, m.h, tm.h, h, weight, accs.h); })); }
 };
 
 }  // namespace
@@ -416,7 +442,8 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def_property_readonly("h", [](KContext& c) { return reinterpret_cast<uintptr_t>(c.h); })
       .def_readonly("device", &KContext::device)
       .def("sync", &KContext::sync).def("set_timing", &KContext::set_timing).def("timings", &KContext::timings)
-      .def("set_k1_form", &KContext::set_k1_form).def("close", &KContext::close);
+      .def("set_k1_form", &KContext::set_k1_form).def("set_option", &KContext::set_option, py::arg("name"), py::arg("value"))
+      .def("get_option", &KContext::get_option, py::arg("name")).def("close", &KContext::close);
 
   py::class_<KComm>(m, "Comm")
       .def_static("unique_id", &KComm::unique_id)

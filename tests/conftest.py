@@ -29,3 +29,22 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def opt(ctx):
+    """Set library options (khg_ctx_set_option) for one test; the previous values come back afterwards.
+    opt("k3_form", 1) ...; opt.k1("pdf") selects a K1 form by name."""
+    saved = []
+
+    class Setter:
+        def __call__(self, name, value):
+            saved.append((name, ctx.set_option(name, int(value))))
+
+        def k1(self, form):
+            saved.append(("k1_form", ctx.get_option("k1_form")))
+            ctx.set_k1_form(form)
+
+    yield Setter()
+    for name, old in reversed(saved):
+        ctx.set_option(name, old)

@@ -373,7 +373,7 @@ def test_faster_decoder_class_like_reference_binding(khg):
         khg.FasterDecoder(fst, khg.FasterDecoderOptions(max_active=1))
 
 
-def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, monkeypatch):
+def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, opt):
     """The wave-parallel order-faithful decoder (prefix-min pruning, atomic per-state minima, first-insertion
     list order) against the one-lane emulation and the oracle's FasterDecoder, on scores that make the beam
     really prune, for the GetCutoff branches (default, max_active, min_active = 0)."""
@@ -387,9 +387,9 @@ def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, monkeypatc
     seen = 0
     for kw in (dict(beam=1.5, retry_beam=6.0), dict(beam=3.0, retry_beam=0.0, max_active=12, min_active=3),
                dict(beam=2.0, retry_beam=8.0, min_active=0), dict(beam=4.0, retry_beam=0.0, max_active=40, min_active=20, beam_delta=0.25)):
-        monkeypatch.delenv("KHG_K2_SERIAL", raising=False)
+        opt("k2_serial", 0)
         rw = us.align(tm, acoustic_scale=1.0, **kw)
-        monkeypatch.setenv("KHG_K2_SERIAL", "1")
+        opt("k2_serial", 1)
         rs = us.align(tm, acoustic_scale=1.0, **kw)
         assert np.array_equal(rw["status"], rs["status"]), kw
         assert np.array_equal(rw["ali"], rs["ali"]), kw

@@ -28,17 +28,21 @@ def _port():
 def _spawn(mode, world, tmp_path):
     port = _port()
     outs = [str(tmp_path / f"{mode}_r{r}.npz") for r in range(world)]
+    # every rank's stderr goes to its own file: a chatty rank can never fill a pipe while another rank waits for it in a collective
+    logs = [open(tmp_path / f"{mode}_r{r}.err", "w+") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, "--rank", str(r), "--world", str(world),
-                               "--port", str(port), "--out", outs[r]], cwd=ROOT, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    errs = []
-    for p in procs:
-        try:
-            _, e = p.communicate(timeout=900)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        errs.append(e)
+                               "--port", str(port), "--out", outs[r]], cwd=ROOT, stderr=logs[r], text=True) for r in range(world)]
+    try:
+        for p in procs:
+            p.wait(timeout=900)
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise
+    finally:
+        errs = []
+        for f in logs:
+            f.seek(0); errs.append(f.read()); f.close()
     for p, e in zip(procs, errs):
         assert p.returncode == 0, e[-3000:]
     return [np.load(o) for o in outs]

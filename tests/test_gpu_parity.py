@@ -56,11 +56,11 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged, k1_form):
 
 @pytest.mark.parametrize("k1", ["f16x2s", "f16x2", "bf16x3", "pdf", "utt"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (24, 20, 13), (12, 128, 80)])
-def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
+def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, opt):
     """Same bound with the means pulled together (many components contribute to every log-sum-exp instead of one)."""
     import dataclasses
 
-    monkeypatch.setenv("KHG_K1", k1)
+    opt.k1(k1)
     m, _, _, ut, cost = build(P, G, D, n_utt=6, seed=P + G + 1, max_phones=5)
     means = (0.12 * m.means).astype(np.float32)
     m2 = dataclasses.replace(m, means=means, means_invvars=(means * m.inv_vars).astype(np.float32))
@@ -89,11 +89,11 @@ def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, monkeypatch):
 
 
 @pytest.fixture(params=["f16x2s", "f16x2", "bf16x3", "pdf", "utt"])
-def k1_form(request, monkeypatch):
+def k1_form(request, opt):
     """Every K1 form: f16x2s (the default: fp16 matrix cores, 3 partial products into one accumulator, feature tiles in LDS and
     pdfs dealt to waves), f16x2 (the same products, two accumulators, frame tiles dealt to waves), bf16x3 (bf16 matrix cores, 6
     partial products) and the two fp32-MFMA tilings, pdf-major and utterance-major."""
-    monkeypatch.setenv("KHG_K1", request.param)
+    opt.k1(request.param)
     return request.param
 
 
@@ -138,13 +138,13 @@ def test_loglikes_wide_dynamic_range(ctx, D, G, k1_form):
     _check_ll(us, dm, m2, gc, ut2)
 
 
-def test_loglikes_f16x2_rescale_and_fallback(ctx, monkeypatch):
+def test_loglikes_f16x2_rescale_and_fallback(ctx, opt):
     """The f16x2 form keeps the set's feature planes while the next model fits their scales, re-packs them when it does
     not, and hands over to the bf16x3 form (exact split, fp32's exponent range) when no scaling fits fp16."""
     import dataclasses
     from kaldi_hmm_gmm_amd import DeviceModel
 
-    monkeypatch.setenv("KHG_K1", "f16x2")
+    opt.k1("f16x2")
     m, gc, om, ut, cost = build(16, 64, 40, n_utt=5, seed=3, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
     ctx.set_timing(True)
@@ -184,14 +184,14 @@ def test_loglikes_f16x2_rescale_and_fallback(ctx, monkeypatch):
     ctx.set_timing(False)
 
 
-def test_loglikes_f16x2s_planes_packed_once_and_fallback(ctx, monkeypatch):
+def test_loglikes_f16x2s_planes_packed_once_and_fallback(ctx, opt):
     """The default form (f16x2s) packs the set's feature planes ONCE -- their exponents depend on the features alone --, re-packs
     only the W image for a new model, and hands over to the two-accumulator f16x2 form when the absolute part of its error bound
     (residual pieces on fp16's subnormal grid) would exceed 2e-6 for the model at hand; results stay inside the fp32 bound."""
     import dataclasses
     from kaldi_hmm_gmm_amd import DeviceModel
 
-    monkeypatch.delenv("KHG_K1", raising=False)
+    opt.k1("auto")
     m, gc, om, ut, cost = build(16, 64, 40, n_utt=5, seed=3, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
     ctx.set_timing(True)
@@ -225,9 +225,9 @@ def test_loglikes_f16x2s_planes_packed_once_and_fallback(ctx, monkeypatch):
 
 
 @pytest.fixture(params=["pdf", "utt"])
-def k1_fp32_form(request, monkeypatch):
+def k1_fp32_form(request, opt):
     """The fp32-MFMA forms, whose contraction is pinned bit for bit to the k-ordered fmaf chain."""
-    monkeypatch.setenv("KHG_K1", request.param)
+    opt.k1(request.param)
     return request.param
 
 
@@ -323,16 +323,16 @@ def test_align_end_to_end(ctx):
 
 @pytest.mark.parametrize("k3_form", ["wave", "block", "valu"])
 @pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (30, 40, 13, True), (12, 128, 80, False)])
-def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, monkeypatch):
+def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
     """All three K3 accumulate kernels: the wave-local MFMA form (default for <= 64 Gaussians, D <= 40), the
-    chunk-per-block MFMA form (KHG_K3_FORM=block; default for wider pdfs / features) and the VALU form
-    (KHG_K3_VALU=1; default above 128 Gaussians)."""
+    chunk-per-block MFMA form (option k3_form = 1; default for wider pdfs / features) and the VALU form
+    (k3_form = 2; default above 128 Gaussians)."""
     from kaldi_hmm_gmm_amd import DeviceAccs
 
     if k3_form == "block":
-        monkeypatch.setenv("KHG_K3_FORM", "block")
+        opt("k3_form", 1)
     elif k3_form == "valu":
-        monkeypatch.setenv("KHG_K3_VALU", "1")
+        opt("k3_form", 2)
 
     m, gc, om, ut, cost = build(P, G, D, n_utt=12, seed=7, ragged=ragged, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
@@ -356,16 +356,16 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, monkeypatch):
 
 @pytest.mark.parametrize("k3_form", ["wave", "block", "valu"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (30, 24, 23), (12, 128, 80)])
-def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, monkeypatch):
+def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, opt):
     """The synthetic model's Gaussians are ~27 sigma apart (posteriors are one-hot, any softmax would do); here the
     means are pulled together so every frame spreads its posterior over many components and the softmax, the
     per-frame normalisation and the gamma-weighted sums are all exercised against the oracle."""
     from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
 
     if k3_form == "block":
-        monkeypatch.setenv("KHG_K3_FORM", "block")
+        opt("k3_form", 1)
     elif k3_form == "valu":
-        monkeypatch.setenv("KHG_K3_VALU", "1")
+        opt("k3_form", 2)
     m, _, _, ut, cost = build(P, G, D, n_utt=12, seed=13, max_phones=5)
     means = (0.12 * m.means).astype(np.float32)
     miv = (means * m.inv_vars).astype(np.float32)
@@ -409,8 +409,8 @@ def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, monkey
     np.testing.assert_allclose(got["occ"], occ64, rtol=2e-4, atol=1e-6)
 
 
-def test_acc_stats_fp32_phase_b_option(ctx, monkeypatch):
-    """KHG_K3_PHASEB=f32 (k3_accumulate_wave32: gamma . x on the fp32 matrix pipe, 256-frame fp32 partial sums widened into a
+def test_acc_stats_fp32_phase_b_option(ctx, opt):
+    """Option k3_phase_b = 1 (k3_accumulate_wave32: gamma . x on the fp32 matrix pipe, 256-frame fp32 partial sums widened into a
     per-workgroup fp64 image): within the statistics' tolerance of the default (products exact in fp64), transition counts
     and frame totals identical, and run-to-run reproducible bit for bit."""
     from kaldi_hmm_gmm_amd import DeviceAccs
@@ -427,7 +427,7 @@ def test_acc_stats_fp32_phase_b_option(ctx, monkeypatch):
         return st
 
     exact = run()
-    monkeypatch.setenv("KHG_K3_PHASEB", "f32")
+    opt("k3_phase_b", 1)
     a, b = run(), run()
     for k in ("occ", "mean_acc", "var_acc", "trans_acc"):
         assert np.array_equal(a[k], b[k]), k
@@ -438,13 +438,13 @@ def test_acc_stats_fp32_phase_b_option(ctx, monkeypatch):
     np.testing.assert_allclose(a["var_acc"], exact["var_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["var_acc"]).max())
     assert not np.array_equal(a["mean_acc"], exact["mean_acc"])      # it really is the other kernel
     for ny in ("3",):                                                # several blocks per pdf: parked slices, same tolerance
-        monkeypatch.setenv("KHG_K3_NY", ny)
+        opt("k3_ny", int(ny))
         c = run()
         np.testing.assert_allclose(c["mean_acc"], exact["mean_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["mean_acc"]).max())
         np.testing.assert_allclose(c["occ"], exact["occ"], rtol=2e-5, atol=1e-6)
 
 
-def test_acc_stats_reproducible_bit_for_bit(ctx, monkeypatch):
+def test_acc_stats_reproducible_bit_for_bit(ctx, opt):
     """Wave-form K3 (the default for <= 64 Gaussians, D <= 40): stable bucket sort, per-pdf tile order, waves and pdf
     slices folded in a fixed order, one atomic per cell -- repeated passes give identical bits, with one block per pdf
     and with a pdf cut into several blocks (small models), scalars included."""
@@ -454,7 +454,7 @@ def test_acc_stats_reproducible_bit_for_bit(ctx, monkeypatch):
     dm, tm, us = _device(ctx, m, gc, ut, cost)
     us.upload_ali(ut.ref_ali)
     for ny in ("1", "7"):
-        monkeypatch.setenv("KHG_K3_NY", ny)
+        opt("k3_ny", int(ny))
         runs = []
         for _ in range(3):
             accs = DeviceAccs(ctx, dm, tm)

@@ -8,7 +8,7 @@ for sub in "abc":
     d = {}
     for r in csv.DictReader(open(fs[0])):
         kn = r["Kernel_Name"]
-        if kn.startswith(("void k1p_loglikes", "k1p_loglikes", "void k1_loglikes", "k1_loglikes", "void k1b_loglikes", "k1b_loglikes", "void k1h_loglikes", "k1h_loglikes")):
+        if kn.startswith(("void k1p_loglikes", "k1p_loglikes", "void k1_loglikes", "k1_loglikes", "void k1b_loglikes", "k1b_loglikes", "void k1h_loglikes", "k1h_loglikes", "void k1s_loglikes", "k1s_loglikes")):
             d.setdefault(kn.split("(")[0], {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             d[kn.split("(")[0]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for kn, cs in d.items():

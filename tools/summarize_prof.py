@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r1"
-OURS = ("k1_loglikes", "k1p_", "k1b_", "k1h_", "k0b_", "k0h_", "k2_viterbi", "k3_", "k4_", "k0_pack", "c1_", "rocprim", "rccl", "nccl")
+OURS = ("k1_loglikes", "k1p_", "k1b_", "k1h_", "k1s_", "k0b_", "k0h_", "k0s_", "k2_viterbi", "k3_", "k4_", "k0_pack", "c1_", "rocprim", "rccl", "nccl")
 
 
 def short(name):
