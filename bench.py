@@ -50,6 +50,9 @@ def parse():
                          "torch.distributed.all_reduce on a view of the block; khg-f32 = the fp32-wire tolerance experiment; "
                          "host = block summed over gloo on the host (test rig: KHG_BENCH_SHARE_GPU=1 puts every rank on GPU 0, "
                          "where RCCL refuses to form a communicator)")
+    ap.add_argument("--c1-parts", type=int, default=4,
+                    help="--allreduce khg: C1 pipelined behind K3 in this many pdf ranges (khg_acc_stats_reduce); 1 = one all-reduce of the "
+                         "whole block behind K3 (khg_accs_allreduce)")
     return ap.parse_args()
 
 
@@ -284,7 +287,13 @@ def main():
         sets.append(UtteranceSet(ctxs[b % len(ctxs)], tm, fo - fo[0], (fsub.data_ptr(), feats), dim=D, graphs=sub))
     accs = DeviceAccs(ctxs[0], dm, tm)
     acc_t = accs.as_torch() if (dist_on and args.allreduce == "torch") else None
-    comm = make_comm(ctxs[0]) if (dist_on and args.allreduce in ("khg", "khg-f32")) else None   # None in a one-rank group
+    comm = None
+    if dist_on and args.allreduce in ("khg", "khg-f32"):
+        try:
+            comm = make_comm(ctxs[0])             # None in a one-rank group
+        except Exception as ex:                   # a rank without its communicator must not leave the others in a barrier
+            print(f"bench.py: rank {rank}: the library's RCCL communicator could not be formed: {ex}", file=sys.stderr, flush=True)
+            os._exit(3)                           # the launcher (torch.distributed.run) then takes the other ranks down
     host_block = np.zeros(accs.size, np.float64) if args.allreduce == "host" else None
 
     T = np.diff(ut.frame_off)
@@ -319,14 +328,17 @@ def main():
         for s_ in sets:                               # batches alternate between the two streams
             s_.loglikes(dm, reachable_only=not args.full_loglikes)
             s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=False)
-        for s_ in sets:
+        piped = dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1
+        for s_ in sets[:-1] if piped else sets:
             s_.acc_stats(dm, tm, accs)
         for st in streams[1:]:
             ev_b.record(st); streams[0].wait_event(ev_b)
         if dist_on:                                   # C1, on stream 0 right behind K3: no host synchronisation
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(streams[0])
-            if acc_t is not None:
+            if piped:                                 # the last set's K3 with the exchange pipelined behind it by pdf ranges
+                sets[-1].acc_stats_reduce(dm, tm, accs, 1.0, comm, args.c1_parts)
+            elif acc_t is not None:
                 dist.all_reduce(acc_t)                # torch's current stream is stream 0
             elif host_block is not None:
                 _lib.check(_lib.lib.khg_accs_download(ctxs[0].h, accs.h, _lib.ptr(host_block, C.c_double)))
@@ -367,6 +379,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt
     for c in ctxs:
         for name, ms in c.timings():                  # HIP events on the launching stream
             kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
@@ -421,6 +434,14 @@ def main():
                      "value": frames_total * 2 / dt32, "k1_kernel_ms": k1_32,
                      "roofline_frac": k1_flops_per_launch / (k1_32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if k1_32 else None}
         ar_events[:] = ar_events[: args.steps]
+
+    # what every rank did, so that imbalance between the shards is visible on the one line rank 0 prints
+    mine_info = {"rank": rank, "utterances": n_local, "frames": frames_local, "seconds": dt_local,
+                 "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())}}
+    per_rank = [mine_info]
+    if dist_on and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_info)
 
     if rank == 0:
         tm0 = time.perf_counter()
@@ -549,8 +570,13 @@ def main():
             "check": {"acc_total_frames": res["total_frames"], "frames_in_set": frames_global, "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
             "allreduce": args.allreduce if dist_on else None,
+            "c1_pipelined_parts": args.c1_parts if (dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1) else None,
+            "per_rank": per_rank if world > 1 else None,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if out["c1_pipelined_parts"]:
+            out["allreduce_note"] = ("allreduce_ms_per_step spans the LAST set's K3 with the exchange pipelined behind it in %d pdf ranges "
+                                     "(khg_acc_stats_reduce); the RCCL pieces alone are kernel_ms_per_step['c1_allreduce']" % args.c1_parts)
+        if not args.no_cpu_baseline:               # rank 0, whatever N (the other ranks wait at the closing barrier)
             ncpu = min(n_local, 40000)     # enough work for a few seconds of every host core
             fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)

@@ -245,6 +245,17 @@ int khg_acc_stats(khg_ctx *ctx, const khg_model *m, const khg_tm *tm, khg_utts *
  * link RCCL: it binds ncclAllReduce & co. from the librccl already loaded into the process (torch's, the
  * caller's) or loads librccl.so.1 itself.  comm == NULL: a one-rank job, nothing to exchange. */
 int khg_accs_allreduce(khg_ctx *ctx, khg_accs *a, void *comm);
+/* The same sum for the accumulator rows of pdfs [first_pdf, first_pdf + n_pdf) only -- the three contiguous pieces occ / mean_acc /
+ * var_acc of their Gaussians, one RCCL group -- or, with first_pdf < 0, for the transition counts and scalars behind them.  The
+ * ranges of a partition of the pdfs plus the tail add up to khg_accs_allreduce. */
+int khg_accs_allreduce_range(khg_ctx *ctx, khg_accs *a, const khg_model *m, int32_t first_pdf, int32_t n_pdf, void *comm);
+/* khg_acc_stats with C1 PIPELINED behind it: the pdfs are cut into `nparts` ranges (<= 0: 4); while the accumulate kernels of
+ * range i + 1 run on the context's stream, the rows of range i are all-reduced on a second stream of the context; the context's
+ * stream waits for the last piece, so the caller goes on exactly as after khg_acc_stats + khg_accs_allreduce.  For the LAST
+ * khg_acc_stats of a pass only (the block must be complete); comm == NULL: plain khg_acc_stats.  On two ranks the result is
+ * bit-identical to the unpipelined exchange (a + b has one order); on more, each form is reproducible run to run. */
+int khg_acc_stats_reduce(khg_ctx *ctx, const khg_model *m, const khg_tm *tm, khg_utts *u, float weight, khg_accs *a,
+                         void *comm, int32_t nparts);
 /* BASELINE.json configs[4] "fp32 stats vs CPU tolerance check": the same exchange with the block
  * rounded to fp32 for the wire (convert -> ncclAllReduce(sum, fp32) -> widen back into the block):
  * half the xGMI bytes, per-rank partial sums lose their low 29 bits.  comm == NULL: only the rounding. */

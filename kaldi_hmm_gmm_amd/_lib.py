@@ -113,6 +113,8 @@ SIGNATURES = {
     "khg_accs_upload": (C.c_int, [vp, vp, c_f64p]),
     "khg_acc_stats": (C.c_int, [vp, vp, vp, vp, C.c_float, vp]),
     "khg_accs_allreduce": (C.c_int, [vp, vp, vp]),
+    "khg_accs_allreduce_range": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp]),
+    "khg_acc_stats_reduce": (C.c_int, [vp, vp, vp, vp, C.c_float, vp, vp, C.c_int32]),
     "khg_accs_allreduce_f32": (C.c_int, [vp, vp, vp]),
     "khg_comm_unique_id": (C.c_int, [vp]),
     "khg_comm_create": (C.c_int, [vp, C.c_int32, C.c_int32, vp, C.POINTER(vp)]),

@@ -49,6 +49,8 @@ struct khg_ctx {
   static constexpr int NSIDE = 4;
   hipStream_t sides[NSIDE] = {nullptr, nullptr, nullptr, nullptr};  // the serial faithful-decoder kernels run here, beside the main stream's next K1
   int next_side = 0;
+  hipStream_t comm_stream = nullptr;   // C1 pieces run here while K3 continues on `stream` (khg_acc_stats_reduce)
+  hipEvent_t ev_k3 = nullptr, ev_c1 = nullptr;
   bool own_stream = false;
   int32_t* err_flag_d = nullptr;
   float* dump_d = nullptr;          // 256 floats nobody reads (K1 f16x2s: where the pipeline's first, empty value goes)
@@ -118,6 +120,9 @@ extern "C" int khg_ctx_destroy(khg_ctx* c) {
   DEVFREE(c->err_flag_d); DEVFREE(c->dump_d);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   for (auto& s : c->sides) (void)hipStreamDestroy(s);
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+  if (c->ev_k3) (void)hipEventDestroy(c->ev_k3);
+  if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
   delete c;
   return KHG_OK;
 }
@@ -1664,7 +1669,11 @@ extern "C" int khg_accs_upload(khg_ctx* ctx, khg_accs* a, const double* buf) {
   return KHG_OK;
 }
 
-extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc) {
+static int accs_allreduce_pieces(khg_ctx* ctx, khg_accs* a, const khg_model* m, int first_pdf, int n_pdf, void* comm, hipStream_t st);
+static int ctx_comm_stream(khg_ctx* ctx);
+// K3, optionally with C1 pipelined behind it: the pdfs are cut into `nparts` ranges; the accumulate kernels of range i + 1 run on
+// the context's stream while the all-reduce of range i's accumulator rows runs on the context's communication stream.
+static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
   if (!ctx || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
   if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
   if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
@@ -1691,7 +1700,9 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
   a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
   a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
   a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
-  a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr;
+  a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr; a.pdf0 = 0;
+  nparts = std::max(1, std::min(nparts, m->P));
+  if (comm && nparts > 1) { rc = ctx_comm_stream(ctx); if (rc) return rc; }
   if (u->N > 0) {
     const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
     {
@@ -1757,6 +1768,10 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       HIPCHK(hipMemsetAsync(u->k3_llpart_d, 0, sizeof(double) * (size_t)m->P, ctx->stream));
       a.ll_part = u->k3_llpart_d;
       a.part = ny > 1 ? u->k3_part_d : nullptr;
+      for (int part = 0; part < nparts; ++part) {
+      const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      a.pdf0 = p0;
+      {
       KernelTimer kt(ctx, "k3_accumulate");
       // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
       // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
@@ -1767,9 +1782,9 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
   do {                                                                                                                  \
     if (!exact_b && lds32 > 48 * 1024)                                                                                  \
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
-    if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);          \
-    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(m->P, ny), dim3(256), lds32, ctx->stream, a);              \
-    if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(m->P), dim3(256), 0, ctx->stream, a, ny);               \
+    if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(np, ny), dim3(256), lds, ctx->stream, a);            \
+    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(np, ny), dim3(256), lds32, ctx->stream, a);                \
+    if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a, ny);                 \
   } while (0)
       switch (nb) {
         case 1: K3_WAVE_LAUNCH(1); break;
@@ -1778,6 +1793,10 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
         default: K3_WAVE_LAUNCH(4); break;
       }
 #undef K3_WAVE_LAUNCH
+      }
+      if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      }
+      a.pdf0 = 0;
       hipLaunchKernelGGL(k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
     } else if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
@@ -1786,24 +1805,53 @@ extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm,
       // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
       if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
-      KernelTimer kt(ctx, "k3_accumulate");
-      if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-      else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-      else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-      else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+      for (int part = 0; part < nparts; ++part) {
+        const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+        a.pdf0 = p0;
+        {
+          KernelTimer kt(ctx, "k3_accumulate");
+          if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+        }
+        if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      }
+      a.pdf0 = 0;
     } else {
       const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + (maxG | 1) + 4);
       if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
       const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : (const void*)k3_accumulate<20>;
       if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
-      KernelTimer kt(ctx, "k3_accumulate");
-      if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
-      else hipLaunchKernelGGL(k3_accumulate<20>, dim3(m->P, ny), dim3(256), lds, ctx->stream, a);
+      for (int part = 0; part < nparts; ++part) {
+        const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+        a.pdf0 = p0;
+        {
+          KernelTimer kt(ctx, "k3_accumulate");
+          if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL(k3_accumulate<20>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
+        }
+        if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      }
+      a.pdf0 = 0;
     }
     HIPCHK(hipGetLastError());
   }
+  if (comm) {
+    // the rest of the block: all of it when nothing was pipelined, else the transition counts and the scalars; then the kernels'
+    // stream waits for the communication stream
+    if (nparts > 1 && u->N > 0) rc = accs_allreduce_pieces(ctx, acc, m, -1, 0, comm, nullptr);
+    else rc = khg_accs_allreduce(ctx, acc, comm);
+    if (rc) return rc;
+  }
   return KHG_OK;   // asynchronous: kernel-side errors surface at khg_ctx_sync / khg_accs_download
+}
+extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc) {
+  return acc_stats_impl(ctx, m, tm, u, weight, acc, nullptr, 1);
+}
+extern "C" int khg_acc_stats_reduce(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int32_t nparts) {
+  return acc_stats_impl(ctx, m, tm, u, weight, acc, comm, nparts <= 0 ? 4 : nparts);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1819,6 +1867,8 @@ struct RcclApi {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, KhgNcclId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -1835,8 +1885,10 @@ static int rccl_bind() {
   a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
   a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString)
+  if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString || !a.GroupStart || !a.GroupEnd)
     return khg_set_error(KHG_E_UNSUPPORTED, "RCCL library lacks ncclAllReduce / ncclCommInitRank");
   g_rccl = a;
   return KHG_OK;
@@ -1852,6 +1904,60 @@ __global__ __launch_bounds__(256) void c1_widen(const float* __restrict__ src, d
   for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) dst[i] = (double)src[i];
 }
 }  // namespace
+
+static int ctx_comm_stream(khg_ctx* ctx) {
+  if (!ctx->comm_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  if (!ctx->ev_k3) HIPCHK(hipEventCreateWithFlags(&ctx->ev_k3, hipEventDisableTiming));
+  if (!ctx->ev_c1) HIPCHK(hipEventCreateWithFlags(&ctx->ev_c1, hipEventDisableTiming));
+  return KHG_OK;
+}
+// The rows of pdfs [first_pdf, first_pdf + n_pdf) of the block -- occ, mean_acc, var_acc: three contiguous pieces -- or, with
+// first_pdf < 0, the transition counts and scalars behind them, summed over the ranks in ONE RCCL group.  st == nullptr: the
+// pieces run on the context's communication stream BEHIND everything enqueued on its kernel stream so far, and the kernel stream
+// then waits for them only when the tail (first_pdf < 0) has gone out: the pipelined form of khg_acc_stats_reduce.
+static int accs_allreduce_pieces(khg_ctx* ctx, khg_accs* a, const khg_model* m, int first_pdf, int n_pdf, void* comm, hipStream_t st) {
+  int rc = rccl_bind();
+  if (rc) return rc;
+  const bool piped = st == nullptr;
+  if (piped) {
+    rc = ctx_comm_stream(ctx);
+    if (rc) return rc;
+    st = ctx->comm_stream;
+    HIPCHK(hipEventRecord(ctx->ev_k3, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_k3, 0));
+  }
+  struct Piece { double* p; size_t n; } pc[3];
+  int npc = 0;
+  if (first_pdf < 0) {
+    pc[npc++] = Piece{a->trans(), (size_t)a->num_tids + 1 + 8};
+  } else {
+    if (first_pdf + n_pdf > m->P || n_pdf < 0) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_range: pdf range outside the model");
+    const int64_t g0 = m->gauss_off[first_pdf], g1 = m->gauss_off[first_pdf + n_pdf];
+    if (g1 > g0) {
+      pc[npc++] = Piece{a->occ() + g0, (size_t)(g1 - g0)};
+      pc[npc++] = Piece{a->mean() + g0 * a->D, (size_t)((g1 - g0) * a->D)};
+      pc[npc++] = Piece{a->var() + g0 * a->D, (size_t)((g1 - g0) * a->D)};
+    }
+  }
+  {
+    KernelTimer kt(ctx, "c1_allreduce", st);
+    int r = g_rccl.GroupStart();
+    for (int i = 0; i < npc && !r; ++i) r = g_rccl.AllReduce(pc[i].p, pc[i].p, pc[i].n, kNcclFloat64, kNcclSum, comm, st);
+    const int r2 = g_rccl.GroupEnd();
+    if (r || r2) return rccl_fail("ncclAllReduce (range)", r ? r : r2);
+  }
+  if (piped && first_pdf < 0) {
+    HIPCHK(hipEventRecord(ctx->ev_c1, st));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
+  }
+  return KHG_OK;
+}
+extern "C" int khg_accs_allreduce_range(khg_ctx* ctx, khg_accs* a, const khg_model* m, int32_t first_pdf, int32_t n_pdf, void* comm) {
+  if (!ctx || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_range: bad arguments");
+  if (a->sumG != m->sumG || a->D != m->D) return khg_set_error(KHG_E_RUNTIME, "khg_accs_allreduce_range: accumulator / model layouts differ");
+  if (!comm) return KHG_OK;
+  return accs_allreduce_pieces(ctx, a, m, first_pdf, n_pdf, comm, ctx->stream);
+}
 
 extern "C" int khg_comm_unique_id(void* id_out) {
   if (!id_out) return khg_set_error(KHG_E_ARG, "khg_comm_unique_id: id_out is NULL");

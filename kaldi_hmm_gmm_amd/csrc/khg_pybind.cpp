@@ -210,6 +210,10 @@ struct KAccs {
   void close() { if (h) { khg_accs_destroy(h); h = nullptr; } }
   void zero() { Check(khg_accs_zero(ctx->h, h)); }
   uintptr_t device_ptr() { void* p = nullptr; Check(khg_accs_device_ptr(h, &p)); return reinterpret_cast<uintptr_t>(p); }
+  void allreduce_range(KModel& m, int first_pdf, int n_pdf, py::object comm) {
+    void* c = comm.is_none() ? nullptr : comm.cast<KComm*>()->h;
+    Check(NoGil([&] { return khg_accs_allreduce_range(ctx->h, h, m.h, first_pdf, n_pdf, c); }));
+  }
   void allreduce(py::object comm, bool wire_fp32) {
     void* c = comm.is_none() ? nullptr : comm.cast<KComm*>()->h;
     Check(NoGil([&] { return wire_fp32 ? khg_accs_allreduce_f32(ctx->h, h, c) : khg_accs_allreduce(ctx->h, h, c); }));
@@ -425,6 +429,10 @@ struct KUtts {
     Check(NoGil([&] { return khg_ali_download(ctx->h, h, a.mutable_data()); }));
     return py::array(a)[py::slice(0, N, 1)];
   }
+  void acc_stats_reduce(KModel& m, KTransitions& tm, KAccs& accs, float weight, py::object comm, int nparts) {
+    void* c = comm.is_none() ? nullptr : comm.cast<KComm*>()->h;
+    Check(NoGil([&] { return khg_acc_stats_reduce(ctx->h, m.h, tm.h, h, weight, accs.h, c, nparts); }));
+  }
   void acc_stats(KModel& m, KTransitions& tm, KAccs& accs, float weight) { Check(NoGil([&] { return khg_acc_stats(ctx->h, m.h, tm.h, h, weight, accs.h); })); }
 };
 
@@ -478,6 +486,7 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def_readonly("num_tids", &KAccs::num_tids).def_readonly("size", &KAccs::size)
       .def("zero", &KAccs::zero).def("device_ptr", &KAccs::device_ptr)
       .def("allreduce", &KAccs::allreduce, py::arg("comm") = py::none(), py::arg("wire_fp32") = false)
+      .def("allreduce_range", &KAccs::allreduce_range, py::arg("model"), py::arg("first_pdf"), py::arg("n_pdf"), py::arg("comm") = py::none())
       .def("split", &KAccs::split).def("relayout", &KAccs::relayout).def("download_range", &KAccs::download_range)
       .def("download_occ", [](KAccs& a) { return a.download_range(0, a.sumG); })
       .def("download_trans", &KAccs::download_trans).def("download", &KAccs::download).def("upload", &KAccs::upload)
@@ -498,6 +507,8 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
            py::arg("beam_delta") = 0.5f, py::arg("hash_ratio") = 2.0f, py::arg("download") = true)
       .def("upload_ali", &KUtts::upload_ali).def("download_ali", &KUtts::download_ali)
       .def("acc_stats", &KUtts::acc_stats, py::arg("model"), py::arg("tm"), py::arg("accs"), py::arg("weight") = 1.0f)
+      .def("acc_stats_reduce", &KUtts::acc_stats_reduce, py::arg("model"), py::arg("tm"), py::arg("accs"), py::arg("weight") = 1.0f,
+           py::arg("comm") = py::none(), py::arg("nparts") = 4)
       .def("close", &KUtts::close);
 
   // ---- host-side functions (no GPU): gconsts, M-step, merge, transition update, AddTransitionProbs costs ----

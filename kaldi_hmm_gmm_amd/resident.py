@@ -121,10 +121,27 @@ class ResidentEm:
     def accumulate(self, weight: float = 1.0) -> Dict[str, float]:
         """gmm_acc_stats_ali over the shard (scripts/gmm_acc_stats_ali.py:9-58) + the cross-rank sum."""
         self.accs.zero()
-        self.us.acc_stats(self.dm, self.dt, self.accs, weight)
-        self._sum_over_ranks()
+        comm = self._rccl_comm()
+        if comm is not None:          # C1 pipelined behind K3 by pdf ranges, on the library's second stream (khg_acc_stats_reduce)
+            self.us.acc_stats_reduce(self.dm, self.dt, self.accs, weight, comm, 4)
+        else:
+            self.us.acc_stats(self.dm, self.dt, self.accs, weight)
+            self._sum_over_ranks()
         self._tr = self.accs.download_trans()
         return {"total_log_like": self._tr["total_log_like"], "total_frames": self._tr["total_frames"]}
+
+    def _rccl_comm(self):
+        """The library's communicator when torch.distributed runs more than one rank over nccl (one GPU per rank), else None."""
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return None
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl"):
+            return None
+        if not self._comm_made:
+            from .dist import make_comm
+            self._comm, self._comm_made = make_comm(self.ctx), True
+        return self._comm
 
     def _sum_over_ranks(self):
         """C1 when torch.distributed is initialised with more than one rank: the library's own RCCL all-reduce on the

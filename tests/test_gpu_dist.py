@@ -148,6 +148,34 @@ def test_rccl_entry_points_with_a_one_rank_communicator(ctx):
     accs.allreduce(None, wire_fp32=True)                   # only the rounding
     ctx.sync()
     assert np.array_equal(accs.download_range(0, accs.size), buf.astype(np.float32).astype(np.float64))
+    # C1 pipelined behind K3 by pdf ranges (khg_acc_stats_reduce) and the range exchange on its own (khg_accs_allreduce_range):
+    # with one rank every sum is the identity, so the block must come out bit for bit as khg_acc_stats left it -- for the
+    # wave-local K3 and for the block / VALU forms, whose range launches take the pdf offset too
+    for form in (0, 1, 2):
+        old = ctx.set_option("k3_form", form)
+        try:
+            for nparts in (1, 3, 4, 1000):
+                accs.zero()
+                us.acc_stats_reduce(dm, tm, accs, 1.0, comm, nparts)
+                ctx.sync()
+                got = accs.download_range(0, accs.size)
+                accs.zero()
+                us.acc_stats(dm, tm, accs)
+                ctx.sync()
+                assert np.array_equal(got, accs.download_range(0, accs.size)), (form, nparts)
+        finally:
+            ctx.set_option("k3_form", old)
+    accs.zero()
+    us.acc_stats(dm, tm, accs)
+    ctx.sync()
+    assert np.array_equal(accs.download_range(0, accs.size), buf)
+    P = len(m.gauss_off) - 1
+    for p0, n in ((0, P // 3), (P // 3, P - P // 3), (-1, 0)):
+        accs.allreduce_range(dm, p0, n, comm)
+    ctx.sync()
+    assert np.array_equal(accs.download_range(0, accs.size), buf)
+    with pytest.raises(Exception):
+        accs.allreduce_range(dm, P - 1, 5, comm)
     comm.close()
     for o in (accs, us, tm, dm):
         o.close()

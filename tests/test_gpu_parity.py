@@ -99,6 +99,10 @@ def k1_form(request, opt):
 
 def _check_ll(us, dm, m, gc, ut):
     us.loglikes(dm)
+    return _check_ll_only(us, m, gc, ut)
+
+
+def _check_ll_only(us, m, gc, ut):
     got = us.download_loglikes()
     poff, pdfs = us.pdf_lists()
     worst = 0.0
@@ -222,6 +226,37 @@ def test_loglikes_f16x2s_planes_packed_once_and_fallback(ctx, opt):
     k = kernels()
     assert "k1h_pack_x" in k and "k0h_pack_tiles" in k and "k0s_pack_tiles" not in k
     ctx.set_timing(False)
+
+
+def test_two_contexts_on_two_streams_share_one_model(ctx):
+    """Two utterance sets with DIFFERENT scale exponents (features in other units) on two contexts / streams, one model: each
+    set's K1 needs its own fp16 W image of that model; the lazily re-packed image must never be read half-written or overwritten
+    under a running K1 on the other stream (the packs and the reads are ordered by events inside the library)."""
+    from kaldi_hmm_gmm_amd import Context, DeviceModel, DeviceTransitions, UtteranceSet
+
+    import dataclasses
+
+    m, gc, om, ut, cost = build(40, 64, 40, n_utt=24, seed=5, max_phones=8)
+    ctx2 = Context(0)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    us_a = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
+    # set B: the SAME model on features stretched by 4 / shrunk by 4 in alternating dimensions -> other feature exponents
+    sc = np.ones(40, np.float32); sc[::2] = 4.0; sc[1::2] = 0.25
+    ut_c = dataclasses.replace(ut, feats=(ut.feats * sc).astype(np.float32))
+    us_b = UtteranceSet(ctx2, tm, ut_c.frame_off, ut_c.feats, graphs=ut.graphs)
+    for form in ("f16x2s", "f16x2", "bf16x3"):
+        ctx.set_k1_form(form); ctx2.set_k1_form(form)
+        for _ in range(6):                              # alternate without synchronising: packs and reads interleave on the two streams
+            us_a.loglikes(dm)
+            us_b.loglikes(dm)
+        ctx.sync(); ctx2.sync()
+        _check_ll_only(us_a, m, gc, ut)
+        _check_ll_only(us_b, m, gc, ut_c)
+    ctx.set_k1_form("auto")
+    for o in (us_b, us_a, tm, dm):
+        o.close()
+    ctx2.close()
 
 
 @pytest.fixture(params=["pdf", "utt"])
