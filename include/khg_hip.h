@@ -319,6 +319,28 @@ int khg_model_set_weights(khg_ctx *ctx, khg_model *m, const float *weights_h);
 int khg_model_mle_update(khg_ctx *ctx, khg_model *m, const khg_accs *a, const khg_mle_options *o,
                          uint16_t flags, float *objf_change, float *count, int32_t *floored_elems,
                          int32_t *floored_gauss, int32_t *removed);
+/* The SHARDED M-step of a multi-GPU job (MleAmDiagGmmUpdate is independent per pdf, csrc/mle-am-diag-gmm.cc:153-202): rank r of
+ * nranks owns the pdfs [P r / nranks, P (r + 1) / nranks).  `a` holds the rank's LOCAL sums (no khg_accs_allreduce before): its
+ * mean / variance rows are ncclReduce'd to their owners by pdf range, the occupancies all-reduced (every rank's mixing-up targets need
+ * them; the transition counts and scalars are NOT touched: khg_accs_allreduce_range with first_pdf < 0), every rank updates its own
+ * pdfs, the rewritten rows and per-pdf results are ncclBroadcast from their owners, and every rank finishes on the complete model
+ * (compaction when Gaussians were removed, images): bit-identical to khg_model_mle_update on the all-reduced block on two ranks
+ * (and with one), (nranks - 1) / nranks x (accumulator + parameter bytes) on the wire per rank instead of 2 (nranks - 1) / nranks x
+ * accumulator bytes.  comm == NULL or nranks == 1: khg_model_mle_update. */
+int khg_model_mle_update_sharded(khg_ctx *ctx, khg_model *m, khg_accs *a, const khg_mle_options *o, uint16_t flags, void *comm,
+                                 int32_t nranks, int32_t rank, float *objf_change, float *count, int32_t *floored_elems,
+                                 int32_t *floored_gauss, int32_t *removed);
+/* Its pieces, for callers that move the rows themselves (ranks that cannot share device buffers): the update of pdfs [first_pdf,
+ * first_pdf + n_pdf) alone (rows rewritten in place in the old layout, one 32-byte result per pdf kept on the handle); the rows of a
+ * range + its results to / from the host (any pointer may be NULL); the finish on the complete rows and results. */
+int khg_model_mle_update_range(khg_ctx *ctx, khg_model *m, const khg_accs *a, const khg_mle_options *o, uint16_t flags,
+                               int32_t first_pdf, int32_t n_pdf);
+int khg_model_mle_rows_download(khg_ctx *ctx, khg_model *m, int32_t first_pdf, int32_t n_pdf, float *weights_h, float *gconsts_h,
+                                float *means_invvars_h, float *inv_vars_h, void *results_h /* 32 n_pdf bytes */);
+int khg_model_mle_rows_upload(khg_ctx *ctx, khg_model *m, int32_t first_pdf, int32_t n_pdf, const float *weights_h,
+                              const float *gconsts_h, const float *means_invvars_h, const float *inv_vars_h, const void *results_h);
+int khg_model_mle_update_finish(khg_ctx *ctx, khg_model *m, float *objf_change, float *count, int32_t *floored_elems,
+                                int32_t *floored_gauss, int32_t *removed);
 /* Mixing up on the handle: AmDiagGmm::SplitByCount's per-pdf DiagGmm::Split (csrc/am-diag-gmm.cc:72-90, csrc/diag-gmm.cc:780-851)
  * to targets_h[p] >= current components (the caller computes them with GetSplitTargets, csrc/model-common.cc:29-70, from
  * the per-pdf occupancies -- khg_accs_download_range(0, sumG)).  The reference draws the perturbations from the process-global

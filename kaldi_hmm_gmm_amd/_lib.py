@@ -131,6 +131,12 @@ SIGNATURES = {
     "khg_diag_gmm_merge": (C.c_int, [c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p]),
     "khg_model_set_weights": (C.c_int, [vp, vp, c_f32p]),
     "khg_model_mle_update": (C.c_int, [vp, vp, vp, C.POINTER(MleOptionsC), C.c_uint16, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p]),
+    "khg_model_mle_update_sharded": (C.c_int, [vp, vp, vp, C.POINTER(MleOptionsC), C.c_uint16, vp, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                              c_i32p, c_i32p, c_i32p]),
+    "khg_model_mle_update_range": (C.c_int, [vp, vp, vp, C.POINTER(MleOptionsC), C.c_uint16, C.c_int32, C.c_int32]),
+    "khg_model_mle_rows_download": (C.c_int, [vp, vp, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, vp]),
+    "khg_model_mle_rows_upload": (C.c_int, [vp, vp, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, vp]),
+    "khg_model_mle_update_finish": (C.c_int, [vp, vp, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p]),
     "khg_model_split": (C.c_int, [vp, vp, c_i32p, C.c_float, c_f32p, C.c_int64]),
     "khg_model_num_gauss": (C.c_int, [vp, C.POINTER(C.c_int64), c_i32p]),
     "khg_model_download": (C.c_int, [vp, vp, c_f32p, c_f32p, c_f32p, c_f32p]),

@@ -317,6 +317,8 @@ struct khg_model {
   std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
   float gcmax = 0.0f;              // max |gconst| over the finite ones (valid with wmax)
   int32_t* tile_pdf_d = nullptr;   // tile -> pdf map of the current layout
+  K4Res* k4_res_d = nullptr;       // per-pdf results of the M-step in progress (khg_model_mle_update*)
+  int32_t k4_res_P = 0;
 };
 
 // (Re)build everything derived from gauss_off + the row-major parameters in HBM: the tile offsets, the K1
@@ -396,7 +398,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
@@ -1868,6 +1870,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, KhgNcclId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*GroupStart)() = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;      // optional (sharded M-step)
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -1887,6 +1891,8 @@ static int rccl_bind() {
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
   a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  a.Reduce = reinterpret_cast<decltype(a.Reduce)>(dlsym(h, "ncclReduce"));
+  a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(h, "ncclBroadcast"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString || !a.GroupStart || !a.GroupEnd)
     return khg_set_error(KHG_E_UNSUPPORTED, "RCCL library lacks ncclAllReduce / ncclCommInitRank");
@@ -1896,7 +1902,7 @@ static int rccl_bind() {
 static int rccl_fail(const char* what, int r) {
   return khg_set_error(KHG_E_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
 }
-constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;   // rccl.h: ncclRedOp_t / ncclDataType_t
+constexpr int kNcclSum = 0, kNcclInt8 = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;   // rccl.h: ncclRedOp_t / ncclDataType_t
 __global__ __launch_bounds__(256) void c1_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
   for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) dst[i] = (float)src[i];
 }
@@ -2044,28 +2050,33 @@ extern "C" int khg_model_download(khg_ctx* ctx, const khg_model* m, float* weigh
   return KHG_OK;
 }
 
-extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* acc, const khg_mle_options* o, uint16_t flags,
-                                    float* objf_change, float* count, int32_t* floored_elems, int32_t* floored_gauss,
-                                    int32_t* removed) {
+// The device M-step in two halves, so that it can be SHARDED over ranks by pdf range:
+//   rows:    k4_mle_update on pdfs [p0, p0 + np): their parameter rows are rewritten in place (old layout), one K4Res per pdf;
+//   finish:  totals in pdf order, compaction when some pdf lost Gaussians, the K1 / K3 images -- on the complete rows + results.
+static int mle_update_rows(khg_ctx* ctx, khg_model* m, const khg_accs* acc, const khg_mle_options* o, uint16_t flags, int p0, int np) {
   if (!ctx || !m || !acc || !o) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: bad arguments");
   if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: the model has no weights (khg_model_set_weights)");
   if (acc->D != m->D || acc->sumG != m->sumG)
     return khg_set_error(KHG_E_RUNTIME, "khg_model_mle_update: accumulator / model dimensions do not match");
   if (flags & ~0x7) return khg_set_error(KHG_E_RUNTIME, "Flags in argument do not match the active accumulators");   // mle-diag-gmm.cc:252
+  if (p0 < 0 || np < 0 || p0 + np > m->P) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: pdf range outside the model");
   { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
   const int P = m->P, D = m->D;
   int maxG = 0;
   for (int p = 0; p < P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
   const size_t lds = sizeof(double) * (256 + (size_t)maxG) + sizeof(float) * 5 * (size_t)maxG;
   if (lds > 60 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_mle_update: more than ~2000 Gaussians in one pdf");
-  K4Res* res_d = nullptr;
-  int rc = dev_alloc(&res_d, (size_t)P);
-  if (rc) return rc;
+  if (!m->k4_res_d || m->k4_res_P != P) {
+    DEVFREE(m->k4_res_d);
+    int rc = dev_alloc(&m->k4_res_d, (size_t)P);
+    if (rc) return rc;
+    m->k4_res_P = P;
+  }
   K4Args a;
   a.gauss_off = m->gauss_off_d; a.D = D;
   a.occ = acc->occ(); a.macc = acc->mean(); a.vacc = acc->var();
   a.w = m->weights_d; a.gc = m->gconsts_d; a.miv = m->miv_d; a.iv = m->iv_d;
-  a.res = res_d;
+  a.res = m->k4_res_d;
   a.min_w = o->min_gaussian_weight; a.min_occ = o->min_gaussian_occupancy; a.min_var = o->min_variance;
   double* floor_d = nullptr;
   a.var_floor = nullptr;
@@ -2073,20 +2084,29 @@ extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* 
     std::vector<double> fv(o->variance_floor_vector, o->variance_floor_vector + D);
     int rcf = dev_upload(ctx, &floor_d, fv);
     if (!rcf) { hipError_t ef = hipStreamSynchronize(ctx->stream); if (ef != hipSuccess) rcf = khg_set_error(KHG_E_HIP, hipGetErrorString(ef)); }
-    if (rcf) { DEVFREE(res_d); DEVFREE(floor_d); return rcf; }
+    if (rcf) { DEVFREE(floor_d); return rcf; }
     a.var_floor = floor_d;
   }
-  a.remove_low = o->remove_low_count_gaussians; a.flags = flags;
-  {
+  a.remove_low = o->remove_low_count_gaussians; a.flags = flags; a.pdf0 = p0;
+  if (np > 0) {
     KernelTimer kt(ctx, "k4_mle_update");
-    hipLaunchKernelGGL(k4_mle_update, dim3(P), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k4_mle_update, dim3(np), dim3(256), lds, ctx->stream, a);
   }
-  std::vector<K4Res> res((size_t)P);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(res.data(), res_d, sizeof(K4Res) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  DEVFREE(res_d); DEVFREE(floor_d);
+  if (e == hipSuccess && floor_d) e = hipStreamSynchronize(ctx->stream);
+  DEVFREE(floor_d);
   if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  return KHG_OK;
+}
+static int mle_update_finish(khg_ctx* ctx, khg_model* m, float* objf_change, float* count, int32_t* floored_elems, int32_t* floored_gauss,
+                             int32_t* removed) {
+  if (!ctx || !m || !m->k4_res_d || m->k4_res_P != m->P) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_finish: no update in progress");
+  const int P = m->P, D = m->D;
+  std::vector<K4Res> res((size_t)P);
+  hipError_t e = hipMemcpyAsync(res.data(), m->k4_res_d, sizeof(K4Res) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  int rc = KHG_OK;
   // totals in pdf order, float, as MleAmDiagGmmUpdate adds them (csrc/mle-am-diag-gmm.cc:177-193)
   float tot_obj = 0.0f, tot_count = 0.0f;
   int tfe = 0, tfg = 0, trm = 0;
@@ -2134,6 +2154,111 @@ extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* 
   if (floored_gauss) *floored_gauss = tfg;
   if (removed) *removed = trm;
   return KHG_OK;
+}
+extern "C" int khg_model_mle_update(khg_ctx* ctx, khg_model* m, const khg_accs* acc, const khg_mle_options* o, uint16_t flags,
+                                    float* objf_change, float* count, int32_t* floored_elems, int32_t* floored_gauss,
+                                    int32_t* removed) {
+  int rc = mle_update_rows(ctx, m, acc, o, flags, 0, m ? m->P : 0);
+  if (rc) return rc;
+  return mle_update_finish(ctx, m, objf_change, count, floored_elems, floored_gauss, removed);
+}
+extern "C" int khg_model_mle_update_range(khg_ctx* ctx, khg_model* m, const khg_accs* acc, const khg_mle_options* o, uint16_t flags,
+                                          int32_t first_pdf, int32_t n_pdf) {
+  return mle_update_rows(ctx, m, acc, o, flags, first_pdf, n_pdf);
+}
+extern "C" int khg_model_mle_update_finish(khg_ctx* ctx, khg_model* m, float* objf_change, float* count, int32_t* floored_elems,
+                                           int32_t* floored_gauss, int32_t* removed) {
+  return mle_update_finish(ctx, m, objf_change, count, floored_elems, floored_gauss, removed);
+}
+// the rows an update of pdfs [first_pdf, first_pdf + n_pdf) rewrote + its per-pdf results (32 bytes each), to / from the host: the
+// exchange step of the sharded M-step for callers whose ranks cannot share device buffers (the tests' gloo ranks on one GPU)
+static int mle_rows_copy(khg_ctx* ctx, khg_model* m, int p0, int np, float* w, float* gc, float* miv, float* iv, void* res, bool up) {
+  if (!ctx || !m || p0 < 0 || np < 0 || p0 + np > m->P || !m->k4_res_d || m->k4_res_P != m->P)
+    return khg_set_error(KHG_E_ARG, "khg_model_mle_rows: bad arguments (or no update in progress)");
+  const size_t g0 = (size_t)m->gauss_off[p0], ng = (size_t)m->gauss_off[p0 + np] - g0, D = (size_t)m->D;
+  auto cp = [&](float* host, float* dev, size_t n) -> hipError_t {
+    if (!host || n == 0) return hipSuccess;
+    return up ? hipMemcpyAsync(dev, host, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream)
+              : hipMemcpyAsync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  };
+  HIPCHK(cp(w, m->weights_d + g0, ng));
+  HIPCHK(cp(gc, m->gconsts_d + g0, ng));
+  HIPCHK(cp(miv, m->miv_d + g0 * D, ng * D));
+  HIPCHK(cp(iv, m->iv_d + g0 * D, ng * D));
+  if (res && np > 0)
+    HIPCHK(up ? hipMemcpyAsync(m->k4_res_d + p0, res, sizeof(K4Res) * (size_t)np, hipMemcpyHostToDevice, ctx->stream)
+              : hipMemcpyAsync(res, m->k4_res_d + p0, sizeof(K4Res) * (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+extern "C" int khg_model_mle_rows_download(khg_ctx* ctx, khg_model* m, int32_t first_pdf, int32_t n_pdf, float* weights, float* gconsts,
+                                           float* means_invvars, float* inv_vars, void* results) {
+  return mle_rows_copy(ctx, m, first_pdf, n_pdf, weights, gconsts, means_invvars, inv_vars, results, false);
+}
+extern "C" int khg_model_mle_rows_upload(khg_ctx* ctx, khg_model* m, int32_t first_pdf, int32_t n_pdf, const float* weights,
+                                         const float* gconsts, const float* means_invvars, const float* inv_vars, const void* results) {
+  return mle_rows_copy(ctx, m, first_pdf, n_pdf, const_cast<float*>(weights), const_cast<float*>(gconsts), const_cast<float*>(means_invvars),
+                       const_cast<float*>(inv_vars), const_cast<void*>(results), true);
+}
+// SURVEY.md 8f-3 as written: the block is REDUCED by pdf range to its owner (rank r owns pdfs [P r / N, P (r + 1) / N)) instead of
+// all-reduced, every rank updates its own pdfs, the updated rows and per-pdf results are broadcast from their owners, and every rank
+// finishes (compaction, images) on the complete model: (N - 1) / N x (207 + 105) MB per rank on the wire instead of
+// 2 (N - 1) / N x 207 MB at 5000 x 64 x 40.  `acc` holds this rank's LOCAL sums (no khg_accs_allreduce before); on return its
+// occupancies are summed over the ranks, its mean / variance rows are complete only for the rank's own pdfs, and its transition counts
+// and scalars are untouched (khg_accs_allreduce_range with first_pdf < 0 sums those).
+extern "C" int khg_model_mle_update_sharded(khg_ctx* ctx, khg_model* m, khg_accs* acc, const khg_mle_options* o, uint16_t flags,
+                                            void* comm, int32_t nranks, int32_t rank, float* objf_change, float* count,
+                                            int32_t* floored_elems, int32_t* floored_gauss, int32_t* removed) {
+  if (!ctx || !m || !acc || !o || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_sharded: bad arguments");
+  if (!comm || nranks == 1) {
+    int rc = mle_update_rows(ctx, m, acc, o, flags, 0, m->P);
+    return rc ? rc : mle_update_finish(ctx, m, objf_change, count, floored_elems, floored_gauss, removed);
+  }
+  int rc = rccl_bind();
+  if (rc) return rc;
+  if (!g_rccl.Reduce || !g_rccl.Broadcast) return khg_set_error(KHG_E_UNSUPPORTED, "RCCL library lacks ncclReduce / ncclBroadcast");
+  if (acc->D != m->D || acc->sumG != m->sumG) return khg_set_error(KHG_E_RUNTIME, "khg_model_mle_update_sharded: accumulator / model dimensions do not match");
+  const int P = m->P;
+  const int64_t D = m->D;
+  auto range = [&](int r, int* p0, int* np) { *p0 = (int)((int64_t)P * r / nranks); *np = (int)((int64_t)P * (r + 1) / nranks) - *p0; };
+  {
+    KernelTimer kt(ctx, "c1_reduce_by_pdf_range");
+    int r = g_rccl.GroupStart();
+    // occupancies: all of them to everybody (1 / (2 D + 1) of the block; the mixing-up targets need every pdf's) ...
+    if (!r && acc->sumG > 0) r = g_rccl.AllReduce(acc->occ(), acc->occ(), (size_t)acc->sumG, kNcclFloat64, kNcclSum, comm, ctx->stream);
+    for (int o2 = 0; o2 < nranks && !r; ++o2) {      // ... first- and second-order sums: each pdf range to its owner only
+      int p0, np;
+      range(o2, &p0, &np);
+      const int64_t g0 = m->gauss_off[p0], ng = m->gauss_off[p0 + np] - g0;
+      if (ng == 0) continue;
+      r = g_rccl.Reduce(acc->mean() + g0 * D, acc->mean() + g0 * D, (size_t)(ng * D), kNcclFloat64, kNcclSum, o2, comm, ctx->stream);
+      if (!r) r = g_rccl.Reduce(acc->var() + g0 * D, acc->var() + g0 * D, (size_t)(ng * D), kNcclFloat64, kNcclSum, o2, comm, ctx->stream);
+    }
+    const int r2 = g_rccl.GroupEnd();
+    if (r || r2) return rccl_fail("ncclReduce (sharded M-step)", r ? r : r2);
+  }
+  int p0, np;
+  range(rank, &p0, &np);
+  rc = mle_update_rows(ctx, m, acc, o, flags, p0, np);
+  if (rc) return rc;
+  {
+    KernelTimer kt(ctx, "c1_broadcast_rows");
+    int r = g_rccl.GroupStart();
+    for (int o2 = 0; o2 < nranks && !r; ++o2) {
+      int q0, nq;
+      range(o2, &q0, &nq);
+      const int64_t g0 = m->gauss_off[q0], ng = m->gauss_off[q0 + nq] - g0;
+      if (nq > 0) r = g_rccl.Broadcast(m->k4_res_d + q0, m->k4_res_d + q0, sizeof(K4Res) * (size_t)nq, kNcclInt8, o2, comm, ctx->stream);
+      if (ng == 0) continue;
+      if (!r) r = g_rccl.Broadcast(m->weights_d + g0, m->weights_d + g0, (size_t)ng, kNcclFloat32, o2, comm, ctx->stream);
+      if (!r) r = g_rccl.Broadcast(m->gconsts_d + g0, m->gconsts_d + g0, (size_t)ng, kNcclFloat32, o2, comm, ctx->stream);
+      if (!r) r = g_rccl.Broadcast(m->miv_d + g0 * D, m->miv_d + g0 * D, (size_t)(ng * D), kNcclFloat32, o2, comm, ctx->stream);
+      if (!r) r = g_rccl.Broadcast(m->iv_d + g0 * D, m->iv_d + g0 * D, (size_t)(ng * D), kNcclFloat32, o2, comm, ctx->stream);
+    }
+    const int r2 = g_rccl.GroupEnd();
+    if (r || r2) return rccl_fail("ncclBroadcast (sharded M-step)", r ? r : r2);
+  }
+  return mle_update_finish(ctx, m, objf_change, count, floored_elems, floored_gauss, removed);
 }
 
 extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* targets, float perturb, const float* randn, int64_t n_randn) {

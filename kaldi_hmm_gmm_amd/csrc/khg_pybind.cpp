@@ -149,6 +149,12 @@ struct KModel {
     Check(khg_model_set_weights(ctx->h, h, w.data()));
   }
   py::dict mle_update(KAccs& accs, py::object opts, int flags);
+  py::dict mle_result(float oc, float cnt, int32_t fe, int32_t fg, int32_t rm);
+  py::dict mle_update_sharded(KAccs& accs, py::object opts, int flags, py::object comm);
+  void mle_update_range(KAccs& accs, py::object opts, int flags, int first_pdf, int n_pdf);
+  py::dict mle_rows_download(int first_pdf, int n_pdf);
+  void mle_rows_upload(py::dict d);
+  py::dict mle_update_finish();
   void scale_weights(Arr<int32_t> pdfs, float scale) { Check(khg_model_scale_weights(ctx->h, h, (int32_t)pdfs.shape(0), pdfs.data(), scale)); }
   void split(Arr<int32_t> targets, float perturb, py::object randn) {
     if (targets.shape(0) != num_pdfs) throw py::value_error("split: one target per pdf");
@@ -267,10 +273,8 @@ struct KAccs {
   }
 };
 
-py::dict KModel::mle_update(KAccs& accs, py::object opts, int flags) {
-  khg_mle_options o;
+static void ParseMleOptions(py::object opts, int dim, khg_mle_options& o, Arr<double>& vfv) {
   khg_mle_options_default(&o);
-  Arr<double> vfv;                                    // keeps the floor vector alive for the call
   if (!opts.is_none()) {
     o.min_gaussian_weight = opts.attr("min_gaussian_weight").cast<float>();
     o.min_gaussian_occupancy = opts.attr("min_gaussian_occupancy").cast<float>();
@@ -284,9 +288,8 @@ py::dict KModel::mle_update(KAccs& accs, py::object opts, int flags) {
       }
     }
   }
-  float oc = 0, cnt = 0;
-  int32_t fe = 0, fg = 0, rm = 0;
-  Check(NoGil([&] { return khg_model_mle_update(ctx->h, h, accs.h, &o, (uint16_t)(flags & 0xFFFF), &oc, &cnt, &fe, &fg, &rm); }));
+}
+py::dict KModel::mle_result(float oc, float cnt, int32_t fe, int32_t fg, int32_t rm) {
   if (rm) {
     Arr<int32_t> go({(py::ssize_t)num_pdfs + 1});
     Check(khg_model_num_gauss(h, nullptr, go.mutable_data()));
@@ -295,6 +298,61 @@ py::dict KModel::mle_update(KAccs& accs, py::object opts, int flags) {
   py::dict d;
   d["objf_change"] = oc; d["count"] = cnt; d["floored_elements"] = fe; d["floored_gaussians"] = fg; d["removed"] = rm;
   return d;
+}
+py::dict KModel::mle_update(KAccs& accs, py::object opts, int flags) {
+  khg_mle_options o;
+  Arr<double> vfv;                                    // keeps the floor vector alive for the call
+  ParseMleOptions(opts, dim, o, vfv);
+  float oc = 0, cnt = 0;
+  int32_t fe = 0, fg = 0, rm = 0;
+  Check(NoGil([&] { return khg_model_mle_update(ctx->h, h, accs.h, &o, (uint16_t)(flags & 0xFFFF), &oc, &cnt, &fe, &fg, &rm); }));
+  return mle_result(oc, cnt, fe, fg, rm);
+}
+// the sharded M-step (khg_model_mle_update_sharded) and its pieces
+py::dict KModel::mle_update_sharded(KAccs& accs, py::object opts, int flags, py::object comm) {
+  khg_mle_options o;
+  Arr<double> vfv;
+  ParseMleOptions(opts, dim, o, vfv);
+  KComm* c = comm.is_none() ? nullptr : comm.cast<KComm*>();
+  float oc = 0, cnt = 0;
+  int32_t fe = 0, fg = 0, rm = 0;
+  Check(NoGil([&] { return khg_model_mle_update_sharded(ctx->h, h, accs.h, &o, (uint16_t)(flags & 0xFFFF), c ? c->h : nullptr, c ? c->nranks : 1,
+                                                        c ? c->rank : 0, &oc, &cnt, &fe, &fg, &rm); }));
+  return mle_result(oc, cnt, fe, fg, rm);
+}
+void KModel::mle_update_range(KAccs& accs, py::object opts, int flags, int first_pdf, int n_pdf) {
+  khg_mle_options o;
+  Arr<double> vfv;
+  ParseMleOptions(opts, dim, o, vfv);
+  Check(NoGil([&] { return khg_model_mle_update_range(ctx->h, h, accs.h, &o, (uint16_t)(flags & 0xFFFF), first_pdf, n_pdf); }));
+}
+py::dict KModel::mle_rows_download(int first_pdf, int n_pdf) {
+  if (first_pdf < 0 || n_pdf < 0 || first_pdf + n_pdf > num_pdfs) throw py::value_error("mle_rows_download: pdf range outside the model");
+  const py::ssize_t ng = gauss_off.at(first_pdf + n_pdf) - gauss_off.at(first_pdf);
+  Arr<float> w({ng}), gc({ng}), miv({ng, (py::ssize_t)dim}), iv({ng, (py::ssize_t)dim});
+  py::array_t<uint8_t> res({(py::ssize_t)n_pdf, (py::ssize_t)32});
+  Check(NoGil([&] { return khg_model_mle_rows_download(ctx->h, h, first_pdf, n_pdf, w.mutable_data(), gc.mutable_data(), miv.mutable_data(),
+                                                       iv.mutable_data(), res.mutable_data()); }));
+  py::dict d;
+  d["first_pdf"] = first_pdf; d["n_pdf"] = n_pdf; d["weights"] = w; d["gconsts"] = gc; d["means_invvars"] = miv; d["inv_vars"] = iv; d["results"] = res;
+  return d;
+}
+void KModel::mle_rows_upload(py::dict d) {
+  const int first_pdf = d["first_pdf"].cast<int>(), n_pdf = d["n_pdf"].cast<int>();
+  if (first_pdf < 0 || n_pdf < 0 || first_pdf + n_pdf > num_pdfs) throw py::value_error("mle_rows_upload: pdf range outside the model");
+  const py::ssize_t ng = gauss_off.at(first_pdf + n_pdf) - gauss_off.at(first_pdf);
+  Arr<float> w = d["weights"].cast<Arr<float>>(), gc = d["gconsts"].cast<Arr<float>>(), miv = d["means_invvars"].cast<Arr<float>>(),
+             iv = d["inv_vars"].cast<Arr<float>>();
+  py::array_t<uint8_t, py::array::c_style | py::array::forcecast> res = d["results"].cast<py::array_t<uint8_t, py::array::c_style | py::array::forcecast>>();
+  if (w.size() != ng || gc.size() != ng || miv.size() != ng * dim || iv.size() != ng * dim || res.size() != (py::ssize_t)n_pdf * 32)
+    throw py::value_error("mle_rows_upload: array sizes do not match the pdf range");
+  Check(NoGil([&] { return khg_model_mle_rows_upload(ctx->h, h, first_pdf, n_pdf, w.data(), gc.data(), miv.data(), iv.data(), res.data()); }));
+}
+py::dict KModel::mle_update_finish() {
+  float oc = 0, cnt = 0;
+  int32_t fe = 0, fg = 0, rm = 0;
+  Check(NoGil([&] { return khg_model_mle_update_finish(ctx->h, h, &oc, &cnt, &fe, &fg, &rm); }));
+  return mle_result(oc, cnt, fe, fg, rm);
 }
 
 struct KUtts {
@@ -468,6 +526,11 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def_readonly("gauss_off", &KModel::gauss_off)
       .def("set_weights", &KModel::set_weights)
       .def("mle_update", &KModel::mle_update, py::arg("accs"), py::arg("opts") = py::none(), py::arg("flags") = 0x7)
+      .def("mle_update_sharded", &KModel::mle_update_sharded, py::arg("accs"), py::arg("opts") = py::none(), py::arg("flags") = 0x7,
+           py::arg("comm") = py::none())
+      .def("mle_update_range", &KModel::mle_update_range, py::arg("accs"), py::arg("opts"), py::arg("flags"), py::arg("first_pdf"), py::arg("n_pdf"))
+      .def("mle_rows_download", &KModel::mle_rows_download).def("mle_rows_upload", &KModel::mle_rows_upload)
+      .def("mle_update_finish", &KModel::mle_update_finish)
       .def("scale_weights", &KModel::scale_weights)
       .def("split", &KModel::split, py::arg("targets"), py::arg("perturb_factor"), py::arg("randn"))
       .def("download", &KModel::download, py::arg("weights") = true)

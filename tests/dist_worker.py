@@ -81,8 +81,26 @@ def run_kernels(args):
     own = buf.copy()
     t = torch.from_numpy(buf)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)              # C1 on the host (see the module docstring)
+    # the SHARDED M-step (khg_model_mle_update_range / _rows_* / _finish) on a second copy of the model: this rank
+    # updates its own pdf range, the rows travel over the process group (the stand-in for ncclBroadcast on one GPU), every rank
+    # finishes -- must equal the replicated update below bit for bit
+    from kaldi_hmm_gmm_amd import DeviceModel
+    dm2 = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    accs.upload(buf)
+    P = len(m.gauss_off) - 1
+    rng_of = lambda r: (P * r // args.world, P * (r + 1) // args.world - P * r // args.world)
+    p0, npd = rng_of(args.rank)
+    dm2.mle_update_range(accs, None, 0x7, p0, npd)
+    rows = [None] * args.world
+    dist.all_gather_object(rows, {k: (np.asarray(v) if not isinstance(v, int) else v) for k, v in dm2.mle_rows_download(p0, npd).items()})
+    for r_, rw in enumerate(rows):
+        if r_ != args.rank:
+            dm2.mle_rows_upload(rw)
+    r2 = dm2.mle_update_finish()
+    d2 = dm2.download()
     r, d = kernels_mstep(dm, accs, buf)
     np.savez(args.out, own_block=own, block=buf, ali=ali, mine=mine, removed=r["removed"], objf=r["objf_change"],
+             sharded_removed=r2["removed"], sharded_objf=r2["objf_change"], **{"sharded_" + k: v for k, v in d2.items()},
              **{k: v for k, v in d.items()})
 
 

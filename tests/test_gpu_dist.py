@@ -64,6 +64,11 @@ def test_two_ranks_sharded_em_pass_equals_single_process(ctx, tmp_path):
     for k in PAR:
         assert np.array_equal(got[0][k], got[1][k]), k
     assert int(got[0]["removed"]) == int(got[1]["removed"])
+    # ... and the SHARDED M-step (each rank updates its own pdf range, the rows are exchanged, every rank finishes) gives that model too
+    for r in range(2):
+        for k in PAR:
+            assert np.array_equal(got[r]["sharded_" + k], got[r][k]), (r, k)
+        assert int(got[r]["sharded_removed"]) == int(got[r]["removed"]) and float(got[r]["sharded_objf"]) == float(got[r]["objf"])
 
     # (2) this process, running the two shards one after the other and adding the two blocks (a + b: the sum of two
     # operands does not depend on the order), reproduces the ranks' block, alignments and post-K4 model bit for bit
@@ -176,6 +181,37 @@ def test_rccl_entry_points_with_a_one_rank_communicator(ctx):
     assert np.array_equal(accs.download_range(0, accs.size), buf)
     with pytest.raises(Exception):
         accs.allreduce_range(dm, P - 1, 5, comm)
+    # the sharded M-step through RCCL with one rank (ncclReduce / ncclBroadcast to itself) == the replicated one, Gaussians removed included
+    from kaldi_hmm_gmm_amd import DeviceModel
+    from kaldi_hmm_gmm_amd.mle import MleDiagGmmOptions
+    opts = MleDiagGmmOptions(min_gaussian_occupancy=40.0)
+    dm_a = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    dm_b = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    accs.upload(buf)
+    ra = dm_a.mle_update(accs, opts, 0x7)
+    accs.upload(buf)
+    rb = dm_b.mle_update_sharded(accs, opts, 0x7, comm)
+    assert ra == rb and ra["removed"] > 0
+    da, db = dm_a.download(), dm_b.download()
+    for k in da:
+        assert np.array_equal(da[k], db[k]), k
+    # two "ranks" emulated in this process: two copies of the model each update one half, swap rows, finish
+    dm_c = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    dm_d = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    accs.upload(buf)
+    h = P // 2 + 1
+    dm_c.mle_update_range(accs, opts, 0x7, 0, h)
+    dm_d.mle_update_range(accs, opts, 0x7, h, P - h)
+    dm_d.mle_rows_upload(dm_c.mle_rows_download(0, h))
+    dm_c.mle_rows_upload(dm_d.mle_rows_download(h, P - h))
+    rc_, rd_ = dm_c.mle_update_finish(), dm_d.mle_update_finish()
+    assert rc_ == ra and rd_ == ra
+    for dmx in (dm_c, dm_d):
+        dx = dmx.download()
+        for k in da:
+            assert np.array_equal(da[k], dx[k]), k
+    for o in (dm_a, dm_b, dm_c, dm_d):
+        o.close()
     comm.close()
     for o in (accs, us, tm, dm):
         o.close()
