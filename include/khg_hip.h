@@ -326,7 +326,7 @@ int khg_model_mle_update(khg_ctx *ctx, khg_model *m, const khg_accs *a, const kh
  * pdfs, the rewritten rows and per-pdf results are ncclBroadcast from their owners, and every rank finishes on the complete model
  * (compaction when Gaussians were removed, images): bit-identical to khg_model_mle_update on the all-reduced block on two ranks
  * (and with one), (nranks - 1) / nranks x (accumulator + parameter bytes) on the wire per rank instead of 2 (nranks - 1) / nranks x
- * accumulator bytes.  comm == NULL or nranks == 1: khg_model_mle_update. */
+ * accumulator bytes.  comm == NULL: khg_model_mle_update. */
 int khg_model_mle_update_sharded(khg_ctx *ctx, khg_model *m, khg_accs *a, const khg_mle_options *o, uint16_t flags, void *comm,
                                  int32_t nranks, int32_t rank, float *objf_change, float *count, int32_t *floored_elems,
                                  int32_t *floored_gauss, int32_t *removed);

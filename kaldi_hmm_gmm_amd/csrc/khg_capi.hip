@@ -2210,7 +2210,7 @@ extern "C" int khg_model_mle_update_sharded(khg_ctx* ctx, khg_model* m, khg_accs
                                             void* comm, int32_t nranks, int32_t rank, float* objf_change, float* count,
                                             int32_t* floored_elems, int32_t* floored_gauss, int32_t* removed) {
   if (!ctx || !m || !acc || !o || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_sharded: bad arguments");
-  if (!comm || nranks == 1) {
+  if (!comm) {                      // (a one-rank communicator still goes through RCCL: reductions and broadcasts to itself)
     int rc = mle_update_rows(ctx, m, acc, o, flags, 0, m->P);
     return rc ? rc : mle_update_finish(ctx, m, objf_change, count, floored_elems, floored_gauss, removed);
   }
