@@ -1282,11 +1282,18 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
     rc = m->wimgs_sync.before_read(ctx->stream);
     if (rc) return rc;
     const size_t lds = (size_t)NMAX * k1s_xtile_bytes(KS) + 64;     // + the work-item counter
-    const void* fn = KS == 5 ? (const void*)k1s_loglikes<5> : (const void*)k1s_loglikes<10>;
+    // models of small pdfs (all <= 8 / <= 16 Gaussians, D <= 40): 4 / 2 pdfs share one MFMA tile (k1s_loglikes_packed)
+    int maxG = 0;
+    for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
+    const int pack = (KS != 5 || (ctx->opt[KHG_OPT_K1_DBG] & 16)) ? 1 : maxG <= 8 ? 4 : maxG <= 16 ? 2 : 1;
+    const void* fn = pack == 4 ? (const void*)k1s_loglikes_packed<5, 4> : pack == 2 ? (const void*)k1s_loglikes_packed<5, 2>
+                     : KS == 5 ? (const void*)k1s_loglikes<5> : (const void*)k1s_loglikes<10>;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
       KernelTimer kt(ctx, "k1_loglikes");
-      if (KS == 5) hipLaunchKernelGGL((k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      if (pack == 4) hipLaunchKernelGGL((k1s_loglikes_packed<5, 4>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      else if (pack == 2) hipLaunchKernelGGL((k1s_loglikes_packed<5, 2>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      else if (KS == 5) hipLaunchKernelGGL((k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
       else hipLaunchKernelGGL((k1s_loglikes<10>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
@@ -1733,7 +1740,8 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
           HIPCHK(hipMalloc(&u->sort_tmp_d, need));
           u->sort_tmp_bytes = need;
         }
-        hipLaunchKernelGGL(k3_sort_keys, dim3(gb), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        if (tm->num_tids <= K3_LDS_TIDS) hipLaunchKernelGGL(k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        else hipLaunchKernelGGL(k3_sort_keys<false>, dim3(gb), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
                                                   reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
         hipLaunchKernelGGL(k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);

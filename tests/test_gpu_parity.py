@@ -33,7 +33,9 @@ def _device(ctx, m, gc, ut, cost):
 
 
 @pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, False), (60, 32, 40, True), (30, 64, 40, False),
-                                          (24, 20, 13, True), (12, 128, 80, False)])
+                                          (24, 20, 13, True), (12, 128, 80, False),
+                                          # small pdfs: the default form packs 4 (<= 8 Gaussians) / 2 (<= 16) pdfs into one MFMA tile
+                                          (31, 5, 40, True), (22, 12, 23, True), (9, 16, 40, False), (3, 8, 13, False)])
 def test_loglikes_vs_oracle(ctx, P, G, D, ragged, k1_form):
     m, gc, om, ut, cost = build(P, G, D, n_utt=6, seed=P + G, ragged=ragged, max_phones=5)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
