@@ -483,3 +483,25 @@ def test_graphs_too_large_for_lds_decode_from_hbm_scratch(ctx, beam, retry):
             assert abs(res["like"][u] - want["like"]) <= 1e-5 * abs(want["like"]) + 1e-3
     for o in (us, tm, dm):
         o.close()
+
+
+def test_options_are_validated_and_round_trip(ctx):
+    """khg_ctx_set_option / khg_ctx_get_option: names and numbers, range checks (KHG_E_ARG -> KhgError), previous value returned."""
+    import kaldi_hmm_gmm_amd as khg
+
+    old = ctx.set_option("k3_ny", 3)
+    assert ctx.get_option("k3_ny") == 3 and ctx.get_option(13) == 3
+    assert ctx.set_option(13, old) == 3 and ctx.get_option("k3_ny") == old
+    for name, bad in (("k3_form", 3), ("k1_form", 6), ("k1_order", -1), ("k3_phase_b", 2)):
+        before = ctx.get_option(name)
+        with pytest.raises(khg.KhgError):
+            ctx.set_option(name, bad)
+        assert ctx.get_option(name) == before
+    with pytest.raises(KeyError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(khg.KhgError):
+        ctx.set_option(99, 1)
+    ctx.set_k1_form("f16x2")
+    assert ctx.get_option("k1_form") == 4
+    ctx.set_k1_form("auto")
+    assert ctx.get_option("k1_form") == 0

@@ -35,8 +35,8 @@ def flow_a():
     tm, am, graphs, ali = fresh(); rn = randn(5); out = []
     for it, target in enumerate(mix):
         if it > 0:
-            khg.gmm_boost_silence(am, tm, [ex.SIL], boost=1.25)
-            r = khg.gmm_align_compiled_batch(am, tm, names, graphs, feats, cfg, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+            am_b = khg.gmm_boost_silence(am, tm, [ex.SIL], boost=1.25)      # a boosted COPY aligns (the reference's semantics)
+            r = khg.gmm_align_compiled_batch(am_b, tm, names, graphs, feats, cfg, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
             ali = r["alignment"]
         accs = khg.AccumAmDiagGmm(); accs.init(am, khg.GmmUpdateFlags.kGmmAll)
         ll, tacc = khg.gmm_acc_stats_ali_batch(am, accs, tm, feats, ali)
@@ -72,10 +72,10 @@ cmp(A1, A2, "A-A"); cmp(B1, B2, "B-B"); cmp(A1, B1, "A-B")
 tm, am, graphs, ali = fresh(); rn = randn(5)
 for it, target in enumerate(mix[:4]):
     if it > 0:
-        khg.gmm_boost_silence(am, tm, [ex.SIL], boost=1.25)
+        am_b = khg.gmm_boost_silence(am, tm, [ex.SIL], boost=1.25)
         if it == 3:
             break
-        r = khg.gmm_align_compiled_batch(am, tm, names, graphs, feats, cfg, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+        r = khg.gmm_align_compiled_batch(am_b, tm, names, graphs, feats, cfg, acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
         ali = r["alignment"]
     accs = khg.AccumAmDiagGmm(); accs.init(am, khg.GmmUpdateFlags.kGmmAll)
     ll, tacc = khg.gmm_acc_stats_ali_batch(am, accs, tm, feats, ali)
