@@ -349,6 +349,12 @@ int khg_model_mle_update_finish(khg_ctx *ctx, khg_model *m, float *objf_change, 
  * the host form, gconsts through logf.  The handle is updated in place (call khg_accs_relayout afterwards). */
 int khg_model_split(khg_ctx *ctx, khg_model *m, const int32_t *targets_h, float perturb_factor, const float *randn_h,
                     int64_t n_randn);
+/* Mixing down on the handle: AmDiagGmm::MergeByCount's per-pdf DiagGmm::Merge (csrc/am-diag-gmm.cc:91-108, csrc/diag-gmm.cc:557-759,
+ * MergedComponentsLogdet :761-778) to 1 <= targets_h[p] <= current components (GetSplitTargets again, with "can't merge below 1"
+ * applied by the caller).  One workgroup per pdf, float arithmetic in the order of khg_diag_gmm_merge; the pair merged at each
+ * step is the first maximum of the lower triangle in (i, j < i) order, whatever the thread count.  The handle is updated in
+ * place (call khg_accs_relayout afterwards). */
+int khg_model_merge(khg_ctx *ctx, khg_model *m, const int32_t *targets_h);
 /* total Gaussians and (gauss_off_h may be NULL) the current gauss_off[num_pdfs+1] of the handle */
 int khg_model_num_gauss(const khg_model *m, int64_t *total, int32_t *gauss_off_h);
 /* parameters back to the host (AmDiagGmm::Write needs them); any pointer may be NULL */

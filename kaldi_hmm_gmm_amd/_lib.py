@@ -138,6 +138,7 @@ SIGNATURES = {
     "khg_model_mle_rows_upload": (C.c_int, [vp, vp, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, vp]),
     "khg_model_mle_update_finish": (C.c_int, [vp, vp, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p]),
     "khg_model_split": (C.c_int, [vp, vp, c_i32p, C.c_float, c_f32p, C.c_int64]),
+    "khg_model_merge": (C.c_int, [vp, vp, c_i32p]),
     "khg_model_num_gauss": (C.c_int, [vp, C.POINTER(C.c_int64), c_i32p]),
     "khg_model_download": (C.c_int, [vp, vp, c_f32p, c_f32p, c_f32p, c_f32p]),
     "khg_accs_relayout": (C.c_int, [vp, vp, vp]),

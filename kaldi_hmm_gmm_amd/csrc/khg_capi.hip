@@ -2323,6 +2323,69 @@ extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* target
   return model_pack(ctx, m);
 }
 
+// AmDiagGmm::MergeByCount's per-pdf DiagGmm::Merge (csrc/am-diag-gmm.cc:91-108, csrc/diag-gmm.cc:557-759) on the device model:
+// pdf p keeps targets[p] components (1 <= targets[p] <= its count).  Nothing crosses PCIe but the offsets.
+extern "C" int khg_model_merge(khg_ctx* ctx, khg_model* m, const int32_t* targets) {
+  if (!ctx || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_merge: bad arguments");
+  if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_merge: the model has no weights (khg_model_set_weights)");
+  const int P = m->P, D = m->D;
+  std::vector<int32_t> new_off((size_t)P + 1, 0);
+  std::vector<int64_t> delta_off((size_t)P + 1, 0);
+  bool any = false;
+  for (int p = 0; p < P; ++p) {
+    const int cur = m->gauss_off[p + 1] - m->gauss_off[p];
+    if (targets[p] <= 0 || cur < targets[p])   // csrc/diag-gmm.cc:558-562
+      return khg_set_error(KHG_E_RUNTIME, "Invalid argument for target number of Gaussians (=" + std::to_string(targets[p]) + "), #Gauss = " + std::to_string(cur));
+    new_off[(size_t)p + 1] = new_off[(size_t)p] + targets[p];
+    const bool greedy = targets[p] < cur && targets[p] > 1;
+    delta_off[(size_t)p + 1] = delta_off[(size_t)p] + (greedy ? (int64_t)cur * cur : 0);
+    any = any || targets[p] < cur;
+  }
+  if (!any) return KHG_OK;
+  const int64_t out = new_off[(size_t)P], old = m->sumG;
+  K4MergeArgs a{};
+  int32_t *new_off_d = nullptr, *idx_d = nullptr, *bad_d = nullptr;
+  int64_t* delta_off_d = nullptr;
+  float *scratch = nullptr, *delta_d = nullptr, *w2 = nullptr, *gc2 = nullptr, *miv2 = nullptr, *iv2 = nullptr;
+  int rc = dev_upload(ctx, &new_off_d, new_off);
+  if (!rc) rc = dev_upload(ctx, &delta_off_d, delta_off);
+  if (!rc) rc = dev_alloc(&idx_d, (size_t)2 * old);
+  if (!rc) rc = dev_alloc(&bad_d, 1);
+  if (!rc) rc = dev_alloc(&scratch, (size_t)old * (2 + 4 * (size_t)D));
+  if (!rc) rc = dev_alloc(&delta_d, (size_t)std::max<int64_t>(1, delta_off[(size_t)P]));
+  if (!rc) rc = dev_alloc(&w2, (size_t)out);
+  if (!rc) rc = dev_alloc(&gc2, (size_t)out);
+  if (!rc) rc = dev_alloc(&miv2, (size_t)out * D);
+  if (!rc) rc = dev_alloc(&iv2, (size_t)out * D);
+  int32_t bad = 0;
+  if (!rc) {
+    a.old_off = m->gauss_off_d; a.new_off = new_off_d; a.D = D;
+    a.w = m->weights_d; a.gc = m->gconsts_d; a.miv = m->miv_d; a.iv = m->iv_d;
+    a.w2 = w2; a.gc2 = gc2; a.miv2 = miv2; a.iv2 = iv2;
+    a.wk = scratch; a.logdet = scratch + old;
+    a.mean = scratch + 2 * old; a.m2 = a.mean + old * D; a.mivk = a.m2 + old * D; a.ivk = a.mivk + old * D;
+    a.gone = idx_d; a.keep = idx_d + old; a.delta = delta_d; a.delta_off = delta_off_d; a.bad = bad_d;
+    hipError_t e = hipMemsetAsync(bad_d, 0, sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess) {
+      KernelTimer kt(ctx, "k4_merge");
+      hipLaunchKernelGGL(k4_merge, dim3(P), dim3(256), 0, ctx->stream, a);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, bad_d, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  }
+  DEVFREE(new_off_d); DEVFREE(delta_off_d); DEVFREE(idx_d); DEVFREE(bad_d); DEVFREE(scratch); DEVFREE(delta_d);
+  if (!rc && (bad & 2)) rc = khg_set_error(KHG_E_RUNTIME, "khg_model_merge: no pair of components left to merge (max_i != max_j && max_i != -1 && max_j != -1)");
+  if (!rc && (bad & 1)) rc = khg_set_error(KHG_E_RUNTIME, "khg_model_merge: not a number in gconst computation");
+  if (rc) { DEVFREE(w2); DEVFREE(gc2); DEVFREE(miv2); DEVFREE(iv2); return rc; }
+  DEVFREE(m->weights_d); DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d);
+  m->weights_d = w2; m->gconsts_d = gc2; m->miv_d = miv2; m->iv_d = iv2;
+  m->gauss_off = new_off;
+  m->sumG = out;
+  return model_pack(ctx, m);
+}
+
 // After khg_model_mle_update removed Gaussians the accumulator block is laid out for fewer rows.
 extern "C" int khg_accs_relayout(khg_ctx* ctx, khg_accs* a, const khg_model* m) {
   if (!ctx || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_relayout: bad arguments");

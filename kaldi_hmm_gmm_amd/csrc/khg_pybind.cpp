@@ -167,6 +167,13 @@ struct KModel {
     Check(khg_model_num_gauss(h, nullptr, go.mutable_data()));
     gauss_off = go;
   }
+  void merge(Arr<int32_t> targets) {
+    if (targets.shape(0) != num_pdfs) throw py::value_error("merge: one target per pdf");
+    Check(NoGil([&] { return khg_model_merge(ctx->h, h, targets.data()); }));
+    Arr<int32_t> go({(py::ssize_t)num_pdfs + 1});
+    Check(khg_model_num_gauss(h, nullptr, go.mutable_data()));
+    gauss_off = go;
+  }
   py::dict download(bool weights) {
     const py::ssize_t G = sumG();
     Arr<float> gc({G}), miv({G, (py::ssize_t)dim}), iv({G, (py::ssize_t)dim});
@@ -533,6 +540,7 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def("mle_update_finish", &KModel::mle_update_finish)
       .def("scale_weights", &KModel::scale_weights)
       .def("split", &KModel::split, py::arg("targets"), py::arg("perturb_factor"), py::arg("randn"))
+      .def("merge", &KModel::merge, py::arg("targets"))
       .def("download", &KModel::download, py::arg("weights") = true)
       .def("close", &KModel::close);
 

@@ -177,7 +177,7 @@ class ResidentEm:
             self.accs.upload(buf)
 
     def update(self, tcfg: MleTransitionUpdateConfig = None, gmm_opts: MleDiagGmmOptions = None, mixup: int = 0,
-               perturb_factor: float = 0.01, power: float = 0.2, min_count: float = 20.0, update_flags: str = "mvwt",
+               mixdown: int = 0, perturb_factor: float = 0.01, power: float = 0.2, min_count: float = 20.0, update_flags: str = "mvwt",
                randn=None) -> Dict[str, float]:
         """gmm_est (scripts/gmm_est.py:8-96) from the resident accumulators; returns its printed statistics."""
         flags = str_to_gmm_flags(update_flags)
@@ -198,12 +198,12 @@ class ResidentEm:
         pdf_occs = None
         sharded = self.sharded_mstep and self._rccl_comm() is not None
         go_before = np.asarray(self.dm.gauss_off).copy()
-        if mixup != 0 and not sharded:      # per-pdf occupancies of the statistics, before the update re-lays the block
+        if (mixup != 0 or mixdown != 0) and not sharded:      # per-pdf occupancies of the statistics, before the update re-lays the block
             occ = self.accs.download_occ()
             pdf_occs = np.asarray([occ[go_before[p]: go_before[p + 1]].sum() for p in range(self.dm.num_pdfs)], np.float32)
         if sharded:
             r = self.dm.mle_update_sharded(self.accs, gmm_opts, int(flags) & 0x7, self._comm)
-            if mixup != 0:                  # the occupancies were all-reduced inside; the block still has the old layout
+            if mixup != 0 or mixdown != 0:  # the occupancies were all-reduced inside; the block still has the old layout
                 occ = self.accs.download_occ()
                 pdf_occs = np.asarray([occ[go_before[p]: go_before[p + 1]].sum() for p in range(len(go_before) - 1)], np.float32)
         else:
@@ -214,6 +214,15 @@ class ResidentEm:
         tot_like, tot_t = np.float32(tr["total_log_like"]), np.float32(tr["total_frames"])
         info.update(gmm_objf_impr=r["objf_change"], gmm_count=r["count"], frames=float(tot_t),
                     avg_like=float(tot_like / tot_t) if tot_t else float("nan"), removed=r["removed"])
+        if mixdown != 0:
+            # AmDiagGmm::MergeByCount (csrc/am-diag-gmm.cc:91-108) on the device model (khg_model_merge), before mixing up
+            # like scripts/gmm_est.py:70-84
+            targets = np.asarray(get_split_targets(pdf_occs, mixdown, power, min_count), np.int64)
+            cur = np.diff(self.dm.gauss_off)
+            tgt = np.minimum(np.where(targets == 0, 1, targets), cur).astype(np.int32)      # "can't merge below 1"
+            if (tgt < cur).any():
+                self.dm.merge(tgt)
+                self.accs.relayout(self.dm)
         if mixup != 0:
             # AmDiagGmm::SplitByCount (csrc/am-diag-gmm.cc:72-90) on the device model (khg_model_split): nothing comes down
             # but the occupancies; the normal deviates are drawn here in the order DiagGmm::Split would consume them

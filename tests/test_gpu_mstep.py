@@ -281,3 +281,68 @@ def test_device_split_equals_host_split(ctx):
         dm.split(np.maximum(tgt - 1, 1).astype(np.int32), 0.01, normals)
     for o in (us, tm, dm):
         o.close()
+
+
+@pytest.mark.parametrize("shape", [(11, 24, 13), (4, 70, 40)])
+def test_device_merge_equals_host_merge(ctx, shape):
+    """khg_model_merge (DiagGmm::Merge per pdf on the device, csrc/diag-gmm.cc:557-759) == the host form
+    (khg_diag_gmm_merge through DiagGmm.merge): same component counts; weights / inv_vars / means_invvars to 2e-5 relative
+    (the pair costs go through the device logf, <= 2 ulp from glibc's, the merged parameters themselves through the same
+    float operations), gconsts to 1e-4 absolute + 1e-5 relative; targets of 1 (the global-moments branch), of the current
+    size (left alone, bit for bit) and in between; invalid targets are errors with the reference's wording."""
+    import kaldi_hmm_gmm_amd as khg
+    from kaldi_hmm_gmm_amd import KhgError
+
+    P, Gmax, D = shape
+    rng = np.random.default_rng(17)
+    m = synth.make_model(P, Gmax, D, seed=21, ragged=True)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    cur = np.diff(m.gauss_off)
+    tgt = np.maximum(1, cur - rng.integers(0, np.maximum(cur, 2) - 1)).astype(np.int32)
+    tgt[0] = 1
+    tgt[1] = cur[1]
+    if P > 2:
+        tgt[2] = max(1, cur[2] // 2)
+    want_w, want_miv, want_iv, want_gc = [], [], [], []
+    for p in range(P):
+        a, b = int(m.gauss_off[p]), int(m.gauss_off[p + 1])
+        g = khg.DiagGmm(nmix=b - a, dim=D)
+        g.set_weights(m.weights[a:b]); g.set_invvars(m.inv_vars[a:b]); g._means_invvars = m.means_invvars[a:b].copy(); g.compute_gconsts()
+        if tgt[p] < b - a:
+            g.merge(int(tgt[p]))
+            want_gc.append(g.gconsts)
+        else:
+            want_gc.append(gc[a:b])
+        assert g.num_gauss == tgt[p]
+        want_w.append(g.weights); want_miv.append(g.means_invvars); want_iv.append(g.inv_vars)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    dm.merge(tgt)
+    d = dm.download()
+    assert np.array_equal(d["gauss_off"], np.concatenate([[0], np.cumsum(tgt)]).astype(np.int32))
+    assert np.array_equal(np.asarray(dm.gauss_off), d["gauss_off"])
+    np.testing.assert_allclose(d["weights"], np.concatenate(want_w), rtol=2e-5, atol=0)
+    np.testing.assert_allclose(d["inv_vars"], np.concatenate(want_iv), rtol=2e-5, atol=0)
+    np.testing.assert_allclose(d["means_invvars"], np.concatenate(want_miv), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(d["gconsts"], np.concatenate(want_gc), rtol=1e-5, atol=1e-4)
+    a1, b1 = int(d["gauss_off"][1]), int(d["gauss_off"][2])          # the untouched pdf: bit for bit, gconsts included
+    a0, b0 = int(m.gauss_off[1]), int(m.gauss_off[2])
+    assert np.array_equal(d["weights"][a1:b1], m.weights[a0:b0]) and np.array_equal(d["gconsts"][a1:b1], gc[a0:b0])
+    assert np.array_equal(d["means_invvars"][a1:b1], m.means_invvars[a0:b0])
+    # the merged model scores on the re-packed image
+    us = UtteranceSet(ctx, None, np.array([0, 40], np.int64), rng.standard_normal((40, D)).astype(np.float32))
+    us.set_pdf_list(np.arange(P, dtype=np.int32))
+    us.loglikes(dm)
+    assert np.isfinite(us.download_loglikes()[0]).all()
+    # merging twice the same way gives the same model (no dependence on scratch contents)
+    dm2 = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    dm2.merge(tgt)
+    d2 = dm2.download()
+    for k in ("weights", "gconsts", "means_invvars", "inv_vars"):
+        assert np.array_equal(d[k], d2[k])
+    now = np.diff(d["gauss_off"])
+    with pytest.raises(KhgError, match="Invalid argument for target number of Gaussians"):
+        dm.merge((now + 1).astype(np.int32))
+    with pytest.raises(KhgError, match="Invalid argument for target number of Gaussians"):
+        dm.merge(np.zeros(P, np.int32))
+    dm.merge(now.astype(np.int32))        # nothing to do
+    assert np.array_equal(dm.download()["weights"], d["weights"])

@@ -108,4 +108,22 @@ def test_resident_em_matches_per_call_scripts(ctx):
             assert tm_b.get_transition_log_prob(t) == tm_a.get_transition_log_prob(t)
         likes.append(info_b["avg_like"])
     assert em.num_gauss == 22 and likes[-1] > likes[0] + 1.0
+    # mixing down: AmDiagGmm::MergeByCount on the device model (khg_model_merge) against gmm_est(mixdown=...) on the host
+    am_a, tm_a = _clone(em.sync_host()), copy.deepcopy(tm_b)
+    accs = khg.AccumAmDiagGmm(); accs.init(am_a, khg.GmmUpdateFlags.kGmmAll)
+    ll, tacc = khg.gmm_acc_stats_ali_batch(am_a, accs, tm_a, feats, ali)
+    khg.gmm_est(am_a, accs, tm_a, tacc, tcfg, opts, mixdown=14, update_flags="mvwt", verbose=False)
+    em.accumulate()
+    em.update(tcfg, opts, mixdown=14, update_flags="mvwt")
+    am_b2 = em.sync_host()
+    assert am_a.num_gauss == am_b2.num_gauss == em.num_gauss and em.num_gauss < 22
+    for p in range(am_a.num_pdfs):
+        ga, gb = am_a.get_pdf(p), am_b2.get_pdf(p)
+        assert ga.num_gauss == gb.num_gauss
+        np.testing.assert_allclose(gb.weights, ga.weights, rtol=1e-5)
+        np.testing.assert_allclose(gb.inv_vars, ga.inv_vars, rtol=1e-4)
+        np.testing.assert_allclose(gb.means_invvars, ga.means_invvars, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gb.gconsts, ga.gconsts, rtol=1e-5, atol=1e-4)
+    r = em.align(cfg)                        # and the merged model aligns
+    assert r["num_error"] == 0
     em.close()
