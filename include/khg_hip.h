@@ -25,6 +25,9 @@ extern "C" {
 #define KHG_E_HIP (-2)      /* HIP runtime error (no device, OOM, launch failure)             */
 #define KHG_E_RUNTIME (-3)  /* the reference would throw std::runtime_error here              */
 #define KHG_E_UNSUPPORTED (-4)
+/* largest feature dimension: a 64-frame chunk of rows must fit LDS next to a pdf's posteriors.  D <= 80 runs the MFMA
+ * kernels; 80 < D <= KHG_MAX_DIM the vector-ALU forms of K1 and K3 (correct, not tuned). */
+#define KHG_MAX_DIM 512
 
 typedef struct khg_ctx khg_ctx;
 typedef struct khg_model khg_model;

@@ -24,6 +24,7 @@
 #include "khg_k1_pdfmajor.hip.inc"
 #include "khg_k1_bf16x3.hip.inc"
 #include "khg_k1_f16x2.hip.inc"
+#include "khg_k1_wide.hip.inc"
 #include "khg_k1_f16x2s.hip.inc"
 #include "khg_k2_viterbi.hip.inc"
 #include "khg_k3_accstats.hip.inc"
@@ -331,12 +332,24 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
   for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (m->gauss_off[p + 1] - m->gauss_off[p] + 31) / 32; }
   m->pdf_tile_off[P] = nt;
   m->ntiles = nt;
-  const int TILE = khg_tile_floats(m->KQ);
+  const int TILE = m->KQ ? khg_tile_floats(m->KQ) : 0;
   if (!m->pdf_tile_off_d) { int rc = dev_alloc(&m->pdf_tile_off_d, (size_t)P + 1); if (rc) return rc; }
   if (!m->gauss_off_d) { int rc = dev_alloc(&m->gauss_off_d, (size_t)P + 1); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(m->pdf_tile_off_d, m->pdf_tile_off.data(), sizeof(int32_t) * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(m->gauss_off_d, m->gauss_off.data(), sizeof(int32_t) * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
   if (!m->nhiv_d) { int rc = dev_alloc(&m->nhiv_d, (size_t)m->sumG * D); if (rc) return rc; }
+  if (m->KQ == 0) {
+    // any-dimension model (D > 80): no tile images; K3 still reads -0.5 * inv_vars
+    m->KS = 0;
+    m->wimgb_valid = false;
+    m->wimgh_ex.clear(); m->wimgs_key.clear(); m->wmax.clear();
+    const int64_t n = m->sumG * D;
+    hipLaunchKernelGGL(k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    return KHG_OK;
+  }
   if (!m->wimg_d || m->wimg_tiles < nt) {
     DEVFREE(m->wimg_d);
     int rc = dev_alloc(&m->wimg_d, (size_t)nt * TILE);
@@ -371,13 +384,13 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
                                 const float* gconsts, const float* miv, const float* iv, khg_model** out) {
   if (!ctx || !out || P <= 0 || D <= 0 || !gauss_off || !gconsts || !miv || !iv)
     return khg_set_error(KHG_E_ARG, "khg_model_create: bad arguments");
-  if (D > 80) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_create: feature dim > 80 is not supported by the K1 kernel yet");
+  if (D > KHG_MAX_DIM) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_create: feature dim > " + std::to_string(KHG_MAX_DIM) + " is not supported (a 64-frame chunk of rows must fit LDS)");
   if (gauss_off[0] != 0) return khg_set_error(KHG_E_ARG, "khg_model_create: gauss_off[0] != 0");
   for (int p = 0; p < P; ++p)
     if (gauss_off[p + 1] <= gauss_off[p]) return khg_set_error(KHG_E_ARG, "khg_model_create: every pdf needs >= 1 Gaussian");
   khg_model* m = new khg_model();
   m->ctx = ctx; m->P = P; m->D = D;
-  m->KQ = (D <= 40) ? 10 : 20;
+  m->KQ = (D <= 40) ? 10 : (D <= 80) ? 20 : 0;      // 0: no tile image; K1 / K3 run their any-dimension forms (k1w_loglikes, k3_accumulate<0>)
   m->gauss_off.assign(gauss_off, gauss_off + P + 1);
   m->sumG = gauss_off[P];
   // the row-major parameters go up as they are (K3 and the device M-step read them)
@@ -458,6 +471,8 @@ struct khg_utts {
   const float* feats_d = nullptr; bool own_feats = false;
   int64_t *frame_off_d = nullptr, *state_off_d = nullptr, *pdf_off_d = nullptr, *ll_off_d = nullptr;
   int32_t *pdfs_d = nullptr, *start_d = nullptr;
+  KwChunk* wchunks_d = nullptr;   // 64-frame chunks of the any-dimension K1 (khg_k1_wide.hip.inc)
+  int32_t n_wchunks = 0;
   int64_t *in_off_d = nullptr, *out_off_d = nullptr;
   int32_t *in_src_d = nullptr, *in_col_d = nullptr, *in_tid_d = nullptr, *in_olabel_d = nullptr, *out_inidx_d = nullptr;
   float *in_w_d = nullptr, *final_d = nullptr;
@@ -676,7 +691,7 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   u->pdf_first.clear();     // no graphs behind an explicit list: every frame is needed
   for (int i = 0; i < u->n_utt; ++i) { u->pdf_off[i + 1] = u->pdf_off[i] + n; u->pdfs.insert(u->pdfs.end(), pdfs, pdfs + n); }
   plan_ll(u);
-  DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d);
+  DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d); DEVFREE(u->wchunks_d);
   DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear(); u->tiles_reach = -1;
   DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d); u->tiles2_pto.clear(); u->tiles2_reach = -1;
   DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d); u->p_reach = -1;
@@ -688,7 +703,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   if (!u) return KHG_OK;
   if (u->own_feats) DEVFREE(u->feats_d);
   DEVFREE(u->frame_off_d); DEVFREE(u->state_off_d); DEVFREE(u->pdf_off_d); DEVFREE(u->ll_off_d);
-  DEVFREE(u->pdfs_d); DEVFREE(u->start_d); DEVFREE(u->in_off_d); DEVFREE(u->out_off_d);
+  DEVFREE(u->pdfs_d); DEVFREE(u->wchunks_d); DEVFREE(u->start_d); DEVFREE(u->in_off_d); DEVFREE(u->out_off_d);
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
@@ -733,6 +748,35 @@ static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s)
 static int k1_nf(const khg_ctx* ctx, int KQ) { return KQ != 10 ? 5 : ctx->opt[KHG_OPT_K1_NF] == 5 ? 5 : 6; }
 
 // K1 in pdf-major form: plan (entries grouped by pdf, cut into workgroup slices) + repacked features.
+// D > 80: k1w_loglikes over 64-frame chunks (every cell of every listed pdf; khg_k1_wide.hip.inc)
+static int loglikes_wide(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
+  if (!u->wchunks_d) {
+    std::vector<KwChunk> ch;
+    for (int i = 0; i < u->n_utt; ++i) {
+      const int64_t T = u->frame_off[i + 1] - u->frame_off[i];
+      if (T <= 0 || u->pdf_off[i + 1] == u->pdf_off[i]) continue;
+      for (int64_t t0 = 0; t0 < T; t0 += 64) ch.push_back(KwChunk{i, (int32_t)t0, (int32_t)std::min<int64_t>(64, T - t0), 0});
+    }
+    u->n_wchunks = (int)ch.size();
+    int rc = dev_upload(ctx, &u->wchunks_d, ch);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  KwArgs a;
+  a.feats = u->feats_d; a.frame_off = u->frame_off_d; a.chunks = u->wchunks_d; a.pdf_off = u->pdf_off_d; a.pdfs = u->pdfs_d;
+  a.gauss_off = m->gauss_off_d; a.gconsts = m->gconsts_d; a.means_invvars = m->miv_d; a.nhalf_inv_vars = m->nhiv_d;
+  a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d; a.D = m->D;
+  const size_t lds = sizeof(float) * 64 * (size_t)(m->D | 1);
+  if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k1w_loglikes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (u->n_wchunks > 0) {
+    KernelTimer kt(ctx, "k1_loglikes");
+    hipLaunchKernelGGL(k1w_loglikes, dim3(u->n_wchunks), dim3(256), lds, ctx->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  u->ll_valid = true;
+  return KHG_OK;
+}
+
 static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
   int rc = KHG_OK;
   const int KH = 2 * m->KQ;
@@ -1325,6 +1369,7 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     int form = ctx->opt[KHG_OPT_K1_FORM];
     if (form == KHG_K1_AUTO) form = KHG_K1_F16X2S;
     if (u->N == 0 || u->pdfs.empty()) { u->ll_valid = true; return KHG_OK; }
+    if (m->KQ == 0) return loglikes_wide(ctx, m, u);      // D > 80: one form
     if (form == KHG_K1_F16X2S) {
       rc = loglikes_f16x2s(ctx, const_cast<khg_model*>(m), u, reachable_only);
       if (rc <= 0) return rc;
@@ -1751,7 +1796,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
     const int k3form = ctx->opt[KHG_OPT_K3_FORM];     // 1: the chunk-per-block MFMA form for every shape; 2: the VALU form
-    const bool use_mfma = maxG <= 128 && k3form != 2;
+    const bool use_mfma = maxG <= 128 && k3form != 2 && m->KQ != 0;
     const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && k3form != 1;
     if (use_wave) {
       // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
@@ -1829,9 +1874,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       }
       a.pdf0 = 0;
     } else {
-      const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)4 * m->KQ + (maxG | 1) + 4);
+      const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)(m->KQ ? 4 * m->KQ : (m->D | 1)) + (maxG | 1) + 4);
       if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
-      const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : (const void*)k3_accumulate<20>;
+      const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : m->KQ == 20 ? (const void*)k3_accumulate<20> : (const void*)k3_accumulate<0>;
       if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
       for (int part = 0; part < nparts; ++part) {
@@ -1840,7 +1885,8 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         {
           KernelTimer kt(ctx, "k3_accumulate");
           if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else hipLaunchKernelGGL(k3_accumulate<20>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 20) hipLaunchKernelGGL(k3_accumulate<20>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL(k3_accumulate<0>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
         }
         if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }
