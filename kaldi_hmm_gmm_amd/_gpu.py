@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 
+from . import _kaldi_hmm_gmm_amd as _ext
 from .device import Context, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
 
 _ctx = None
@@ -13,13 +14,16 @@ _ctx = None
 def default_context() -> Context:
     global _ctx
     if _ctx is None:
-        _ctx = Context(int(os.environ.get("KHG_DEVICE", "0")))
+        set_default_context(Context(int(os.environ.get("KHG_DEVICE", "0"))))
     return _ctx
 
 
 def set_default_context(ctx: Context):
+    """The context the single-object calls use (DiagGmm.log_likelihood, AccumDiagGmm.accumulate_from_diag, align_batch ...):
+    shared with the C++ host classes (khg::SetDefaultCtx)."""
     global _ctx
     _ctx = ctx
+    _ext.set_default_context(ctx)
 
 
 def loglikes(gauss_off, gconsts, means_invvars, inv_vars, feats, pdfs):

@@ -3,9 +3,10 @@
 // The reference's host boundary is ONE pybind11 module, `_kaldi_hmm_gmm` (python/csrc/kaldi-hmm-gmm.cc:35-69), whose
 // classes wrap Eigen-backed C++ objects.  This module, `_kaldi_hmm_gmm_amd`, is its counterpart for the accelerated
 // path: C++ classes that own the C-ABI handles (device model, transition tables, resident utterance sets, accumulator
-// block, RCCL communicator) and take / return numpy arrays, plus the host-side functions of the M-step.  The Python
-// classes of kaldi_hmm_gmm_amd (DiagGmm, AmDiagGmm, AccumAmDiagGmm, TransitionModel, ...: the reference's names) are thin
-// shells over it; kaldi_hmm_gmm_amd/device.py re-exports these classes (KHG_BINDING=ctypes selects the ctypes twin).
+// block, RCCL communicator) and take / return numpy arrays, plus the host-side functions of the M-step, plus (BindHost,
+// khg_py_host.cpp / khg_py_hmm.cpp / khg_py_align.cpp) the C++ host classes behind the reference's names: DiagGmm, AmDiagGmm,
+// AccumDiagGmm, AccumAmDiagGmm, HmmTopology, TransitionModel, AlignConfig, DecodableAmDiagGmmScaled, align_utterance_wrapper ...
+// kaldi_hmm_gmm_amd/*.py re-export them.
 // Errors: a non-zero C-ABI status becomes a Python RuntimeError subclass (KhgError), as KHG_ERR does in the reference
 // (csrc/log.h:46-53 -> std::runtime_error -> RuntimeError).
 #include <pybind11/numpy.h>
@@ -503,9 +504,12 @@ struct KUtts {
 
 }  // namespace
 
+void BindHost(py::module_& m, py::object* error_class);      // khg_py_host.cpp: the host classes behind the reference's names
+
 PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
   m.doc() = "pybind11 host surface of libkhg_hip.so (include/khg_hip.h): the accelerated EM hot path of kaldi-hmm-gmm on MI355X";
   m.def("_set_error_class", [](py::object cls) { g_khg_error = cls; });
+  BindHost(m, &g_khg_error);
   m.def("version", [] { return khg_version(); });
   m.attr("ALIGN_DONE") = KHG_ALIGN_DONE; m.attr("ALIGN_ERROR") = KHG_ALIGN_ERROR; m.attr("ALIGN_RETRIED") = KHG_ALIGN_RETRIED;
   m.attr("ALIGN_EXACT_DP") = KHG_ALIGN_EXACT_DP; m.attr("ALIGN_FALLBACK") = KHG_ALIGN_FALLBACK;

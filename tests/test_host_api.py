@@ -540,6 +540,23 @@ def test_pybind11_module_is_the_host_surface():
         for name in methods.split():
             assert hasattr(cls, name), (cls, name)
     assert ext.version() == 100 and issubclass(khg.KhgError, RuntimeError)
+    # the reference-named host classes ARE the extension's C++ classes (csrc/khg_host_{gmm,hmm,align}.cpp), not Python mirrors
+    for name in ("DiagGmm", "AmDiagGmm", "AccumDiagGmm", "AccumAmDiagGmm", "MleDiagGmmOptions", "HmmState", "HmmTopology",
+                 "TransitionModelTuple", "TransitionModel", "MleTransitionUpdateConfig", "AlignConfig", "FasterDecoderOptions",
+                 "DecodableAmDiagGmmUnmapped", "DecodableAmDiagGmmScaled"):
+        assert getattr(khg, name) is getattr(ext, name), name
+    assert khg.align_utterance_wrapper is ext.align_utterance_wrapper and khg.align_batch is ext.align_batch
+    assert khg.get_pdfs_for_phones is ext.get_pdfs_for_phones and khg.ml_objective is ext.ml_objective
+    for cls, methods in ((ext.DiagGmm, "resize set_weights set_means set_invvars compute_gconsts log_likelihood log_likelihoods component_posteriors "
+                                       "split merge perturb generate interpolate remove_component"),
+                         (ext.AmDiagGmm, "init add_pdf get_pdf split_by_count merge_by_count compute_gconsts flat set_flat"),
+                         (ext.AccumDiagGmm, "resize accumulate_from_diag accumulate_from_posteriors accumulate_for_component add smooth_stats"),
+                         (ext.AccumAmDiagGmm, "init accumulate_for_gmm accumulate_for_gmm_two_feats accumulate_from_posteriors add scale get_acc"),
+                         (ext.HmmTopology, "read check topology_for_phone num_pdf_classes min_length"),
+                         (ext.TransitionModel, "transition_id_to_pdf is_self_loop mle_update scaled_trans_cost tuple_to_transition_state "
+                                               "pair_to_transition_id get_transition_log_prob_ignoring_self_loops")):
+        for name in methods.split():
+            assert hasattr(cls, name), (cls, name)
     import torch
     if not torch.cuda.is_available():
         with pytest.raises(khg.KhgError, match="no HIP device"):
