@@ -314,6 +314,7 @@ struct khg_model {
   char* wimgs_d = nullptr;
   int32_t wimgs_tiles = 0;
   std::vector<int32_t> wimgs_key;  // [ex[0..K) of the set, S] the image was packed with (empty: stale)
+  std::vector<int32_t> xs_ex_seen; // element-wise minimum of the feature exponents of the sets scored so far (f16x2s)
   ImgSync wimgs_sync;
   std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
   float gcmax = 0.0f;              // max |gconst| over the finite ones (valid with wmax)
@@ -1225,6 +1226,14 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
   // exponents: every feature column peaks in [2^14, 2^15) (the set's own property), the largest weight column too (S)
   std::vector<int32_t> ex((size_t)K, 0), ew((size_t)K, 0);
   for (int k = 0; k < K; ++k) if (xk[(size_t)k] > 0.0f) ex[(size_t)k] = 14 - std::ilogb(xk[(size_t)k]);
+  // Several utterance sets score against one model (batches of a shard, two contexts): the image is keyed by the feature
+  // exponents, so per-set exponents would re-pack the 100 MB image on every alternating call.  The model keeps the element-wise
+  // minimum of the exponents of the sets it has scored (a smaller exponent never overflows fp16; the absolute part of the error
+  // bound is re-checked below for the exponents actually used) and every set packs its planes with those.
+  if (m->xs_ex_seen.size() == ex.size()) {
+    for (int k = 0; k < K; ++k) ex[(size_t)k] = std::min(ex[(size_t)k], m->xs_ex_seen[(size_t)k]);
+  }
+  m->xs_ex_seen = ex;
   int S = INT_MAX;
   for (int k = 0; k < K; ++k) if (m->wmax[(size_t)k] > 0.0f) S = std::min(S, 14 - std::ilogb(m->wmax[(size_t)k]) + ex[(size_t)k]);
   if (S == INT_MAX) S = 0;

@@ -249,10 +249,19 @@ def test_two_contexts_on_two_streams_share_one_model(ctx):
     us_b = UtteranceSet(ctx2, tm, ut_c.frame_off, ut_c.feats, graphs=ut.graphs)
     for form in ("f16x2s", "f16x2", "bf16x3"):
         ctx.set_k1_form(form); ctx2.set_k1_form(form)
+        for c in (ctx, ctx2):
+            c.sync(); c.set_timing(True); c.timings()
         for _ in range(6):                              # alternate without synchronising: packs and reads interleave on the two streams
             us_a.loglikes(dm)
             us_b.loglikes(dm)
         ctx.sync(); ctx2.sync()
+        names = [n for c in (ctx, ctx2) for n, _ in c.timings()]
+        for c in (ctx, ctx2):
+            c.set_timing(False)
+        if form == "f16x2s":
+            # the model settles on the element-wise minimum of the two sets' feature exponents: one image for both after the
+            # first round, no re-pack of the 100 MB-class image on every alternating call
+            assert names.count("k0s_pack_tiles") <= 2 and names.count("k1s_pack_x") <= 3, names
         _check_ll_only(us_a, m, gc, ut)
         _check_ll_only(us_b, m, gc, ut_c)
     ctx.set_k1_form("auto")
