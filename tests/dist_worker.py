@@ -104,6 +104,52 @@ def run_kernels(args):
              **{k: v for k, v in d.items()})
 
 
+def run_rccl(args):
+    """One rank per GPU (device = rank): the product's own exchange.  K1 -> K2 -> K3 on the shard, then C1 three ways on copies of
+    the rank's block -- khg_accs_allreduce (one ncclAllReduce), khg_acc_stats_reduce (pipelined by pdf ranges behind K3) and the
+    gloo sum on the host as the yardstick -- and the sharded M-step over the communicator (ncclReduce / ncclBroadcast)."""
+    import torch
+    import torch.distributed as dist
+
+    from kaldi_hmm_gmm_amd import Context, DeviceAccs, DeviceModel, _lib
+    from kaldi_hmm_gmm_amd.dist import make_comm, shard_utterances
+    import ctypes as C
+
+    m, gc, cost, ut = kernels_inputs()
+    mine = shard_utterances(np.diff(ut.frame_off), args.world)[args.rank]
+    ndev = torch.cuda.device_count()
+    ctx = Context(args.rank % max(ndev, 1))
+    comm = make_comm(ctx)                                   # None in a one-rank group
+    if comm is None and args.world == 1:
+        from kaldi_hmm_gmm_amd import Comm
+        comm = Comm(ctx, 1, 0, Comm.unique_id())
+    dm, tm, us, accs, buf, ali = kernels_pass(ctx, m, gc, cost, ut, mine)
+    own = buf.copy()
+    host = buf.copy()
+    dist.all_reduce(torch.from_numpy(host), op=dist.ReduceOp.SUM)      # yardstick: the gloo sum on the host
+
+    def download(a):
+        b = np.zeros(a.size, np.float64)
+        _lib.check(_lib.lib.khg_accs_download(ctx.h, a.h, _lib.ptr(b, C.c_double)))
+        return b
+
+    accs.allreduce(comm)                                    # (1) one all-reduce of the whole block
+    whole = download(accs)
+    accs2 = DeviceAccs(ctx, dm, tm)                         # (2) K3 again with C1 pipelined behind it by pdf ranges
+    us.acc_stats_reduce(dm, tm, accs2, 1.0, comm, 4)
+    piped = download(accs2)
+    accs3 = DeviceAccs(ctx, dm, tm)                         # (3) the sharded M-step from the rank's OWN (unreduced) block
+    accs3.upload(own)
+    dm3 = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars, weights=m.weights)
+    r3 = dm3.mle_update_sharded(accs3, None, 0x7, comm)
+    d3 = dm3.download()
+    r, d = kernels_mstep(dm, accs, host)                    # the replicated update from the host-summed block
+    np.savez(args.out, own_block=own, host_block=host, whole_block=whole, piped_block=piped, ali=ali, mine=mine, removed=r["removed"],
+             objf=r["objf_change"], sharded_removed=r3["removed"], sharded_objf=r3["objf_change"],
+             **{"sharded_" + k: v for k, v in d3.items()}, **{k: v for k, v in d.items()})
+    comm.close()
+
+
 def resident_inputs():
     import kaldi_hmm_gmm_amd as khg
     from kaldi_hmm_gmm_amd.training_graph import TrainingGraphCompiler, equal_align, generate_hmm_topo
@@ -162,7 +208,7 @@ def run_resident(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["kernels", "resident"])
+    ap.add_argument("mode", choices=["kernels", "resident", "rccl"])
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
@@ -173,7 +219,7 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
     dist.init_process_group("gloo", rank=args.rank, world_size=args.world)
     try:
-        (run_kernels if args.mode == "kernels" else run_resident)(args)
+        {"kernels": run_kernels, "resident": run_resident, "rccl": run_rccl}[args.mode](args)
         dist.barrier()
     finally:
         dist.destroy_process_group()

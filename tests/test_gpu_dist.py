@@ -238,3 +238,40 @@ def test_bench_launches_its_own_ranks_and_shards_the_one_set():
     assert d2["check"]["avg_loglike_per_frame"] == pytest.approx(d1["check"]["avg_loglike_per_frame"], rel=1e-9)
     assert d2["allreduce_ms_per_step"] is not None and d2["allreduce_bytes"] > 0 and d2["value"] > 0
     assert d2["roofline"]["frac_executed"] <= d2["roofline"]["frac"] < 1.0
+
+
+def _check_rccl_ranks(got, world):
+    PAR = ("gauss_off", "weights", "gconsts", "means_invvars", "inv_vars")
+    tot = sum(g["own_block"] for g in got)
+    scale = np.abs(tot).max()
+    for r in range(world):
+        # the three forms of C1 give the sum of the ranks' blocks: the host (gloo) sum, one ncclAllReduce, the pipelined pieces
+        np.testing.assert_allclose(got[r]["host_block"], tot, rtol=1e-12, atol=1e-12 * scale)
+        np.testing.assert_allclose(got[r]["whole_block"], tot, rtol=1e-12, atol=1e-12 * scale)
+        np.testing.assert_allclose(got[r]["piped_block"], tot, rtol=1e-12, atol=1e-12 * scale)
+        assert np.array_equal(got[r]["whole_block"], got[0]["whole_block"])        # every rank holds the same bits
+        assert np.array_equal(got[r]["piped_block"], got[0]["piped_block"])
+        # the sharded M-step over the communicator = the replicated one on the summed block
+        assert int(got[r]["sharded_removed"]) == int(got[r]["removed"])
+        for k in PAR[:1]:
+            assert np.array_equal(got[r]["sharded_" + k], got[r][k]), (r, k)
+        for k in PAR[1:]:
+            np.testing.assert_allclose(got[r]["sharded_" + k], got[r][k], rtol=2e-6, atol=1e-6, err_msg=k)
+            assert np.array_equal(got[r]["sharded_" + k], got[0]["sharded_" + k]), (r, k)
+
+
+def test_rccl_worker_with_one_rank(tmp_path):
+    """tests/dist_worker.py rccl on the one GPU of this box: a one-rank communicator through every RCCL entry point the
+    multi-GPU run uses (ncclAllReduce whole and in pdf-range groups behind K3, ncclReduce / ncclBroadcast of the sharded M-step)."""
+    _check_rccl_ranks(_spawn("rccl", 1, tmp_path), 1)
+
+
+def test_rccl_two_ranks_on_two_gpus(tmp_path):
+    """The product's own exchange with N > 1: one process per GPU, RCCL over xGMI.  Needs two devices: skipped on the one-GPU
+    test box (the only place this path can run is a multi-GPU node)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL does not form a communicator with two ranks on one device)")
+    world = 2 if n < 4 else 4
+    _check_rccl_ranks(_spawn("rccl", world, tmp_path), world)
