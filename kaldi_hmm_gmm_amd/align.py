@@ -9,7 +9,7 @@ from typing import List, Sequence
 import numpy as np
 
 from . import device  # noqa: F401
-from ._kaldi_hmm_gmm_amd import (AlignConfig, DecodableAmDiagGmmScaled, DecodableAmDiagGmmUnmapped,  # noqa: F401
+from ._kaldi_hmm_gmm_amd import (AlignConfig, DecodableAmDiagGmmScaled, DecodableAmDiagGmmUnmapped, DecodableInterface,  # noqa: F401
                                  FasterDecoderOptions, align_batch, align_utterance_wrapper)
 from ._lib import KhgError
 from .device import ALIGN_ERROR, ALIGN_RETRIED, INT32_MAX  # noqa: F401

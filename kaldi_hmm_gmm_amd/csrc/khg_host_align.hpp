@@ -32,17 +32,28 @@ struct GraphsCsr {                   // fst::VectorFst<StdArc> per utterance, co
   std::vector<float> weight, final_w;
 };
 
+// csrc/decodable-itf.h: what a decoder asks of an acoustic model (1-based index, 0-based frame).  The HIP kernels read scores from
+// K1's matrices, so the classes below are what the alignment entry points accept; the interface itself is there for callers
+// that score frames from Python or C++ through the reference's protocol.
+class DecodableInterface {
+ public:
+  virtual ~DecodableInterface() = default;
+  virtual float LogLikelihood(int frame, int index) const = 0;
+  virtual bool IsLastFrame(int frame) const = 0;
+  virtual int NumFramesReady() const { throw Error("NumFramesReady() not implemented for this decodable type."); }
+  virtual int NumIndices() const = 0;
+};
+
 // csrc/decodable-am-diag-gmm.h:30-78: (frame, pdf-id + 1) -> log-likelihood.  Scores for every pdf are produced by one K1 launch
 // on first use and kept (the reference's one-frame cache).
-class DecodableAmDiagGmmUnmapped {
+class DecodableAmDiagGmmUnmapped : public DecodableInterface {
  public:
   DecodableAmDiagGmmUnmapped(std::shared_ptr<AmDiagGmm> am, const float* feats, int64_t T, int D);
-  virtual ~DecodableAmDiagGmmUnmapped() = default;
-  virtual float LogLikelihood(int frame, int index) const { return ZeroBased(frame, index - 1); }
+  float LogLikelihood(int frame, int index) const override { return ZeroBased(frame, index - 1); }
   float ZeroBased(int frame, int state) const;
-  int NumFramesReady() const { return (int)T_; }
-  virtual int NumIndices() const { return am_->NumPdfs(); }
-  bool IsLastFrame(int frame) const;
+  int NumFramesReady() const override { return (int)T_; }
+  int NumIndices() const override { return am_->NumPdfs(); }
+  bool IsLastFrame(int frame) const override;
   const std::shared_ptr<AmDiagGmm>& am() const { return am_; }
   const std::vector<float>& feats() const { return feats_; }
   int Dim() const { return D_; }

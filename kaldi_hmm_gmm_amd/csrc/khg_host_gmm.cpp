@@ -606,6 +606,73 @@ float MlObjective(const DiagGmm& gmm, const AccumDiagGmm& acc) {
   return obj;
 }
 
+std::string MapDiagGmmOptions::ToString() const {
+  char buf[160];
+  std::snprintf(buf, sizeof(buf), "MapDiagGmmOptions(mean_tau=%g, variance_tau=%g, weight_tau=%g)", (double)mean_tau, (double)variance_tau, (double)weight_tau);
+  return buf;
+}
+
+std::pair<float, float> MapDiagGmmUpdate(const MapDiagGmmOptions& cfg, const AccumDiagGmm& acc, int flags, DiagGmm* gmm) {
+  KHG_REQUIRE(gmm != nullptr, "gmm != NULL assertion failed");
+  KHG_REQUIRE(!(flags & ~acc.Flags()), "Flags in argument do not match the active accumulators");
+  KHG_REQUIRE(acc.NumGauss() == gmm->NumGauss() && acc.Dim() == gmm->Dim(), "diag_gmm_acc.NumGauss() == gmm->NumGauss() && diag_gmm_acc.Dim() == gmm->Dim() assertion failed");
+  const int G = gmm->NumGauss(), D = gmm->Dim();
+  double occ_sum = 0.0;
+  for (double o : acc.occupancy()) occ_sum += o;
+  gmm->ComputeGconsts();
+  const float obj_old = MlObjective(*gmm, acc);
+  // DiagGmmNormal (csrc/diag-gmm-normal.cc:14-20): everything in double
+  std::vector<double> w((size_t)G), vars((size_t)G * D), means((size_t)G * D);
+  for (int g = 0; g < G; ++g) w[(size_t)g] = (double)gmm->weights()[(size_t)g];
+  for (size_t i = 0; i < vars.size(); ++i) { vars[i] = 1.0 / (double)gmm->inv_vars()[i]; means[i] = (double)gmm->means_invvars()[i] * vars[i]; }
+  const std::vector<double> old_means = means;          // CopyToDiagGmm's `oldg`
+  const double mean_tau = cfg.mean_tau, var_tau = cfg.variance_tau, w_tau = cfg.weight_tau;
+  for (int i = 0; i < G; ++i) {
+    const double occ = acc.occupancy()[(size_t)i];
+    w[(size_t)i] = (occ + w[(size_t)i] * w_tau) / (occ_sum + w_tau);      // the weight tau is a tau for the whole state
+    double* mu = &means[(size_t)i * D];
+    double* var = &vars[(size_t)i * D];
+    if (occ > 0.0 && (flags & kGmmMeans)) {
+      const double a = 1.0 / (occ + mean_tau), b = mean_tau / (occ + mean_tau);
+      for (int d = 0; d < D; ++d) { double m = acc.mean_accumulator()[(size_t)i * D + d] * a; m += mu[d] * b; mu[d] = m; }
+    }
+    if (occ > 0.0 && (flags & kGmmVariances)) {
+      // E((x - mu)^2) = E(x^2) + mu^2 - 2 mu E(x) around the (updated) mean, then the tau weighting
+      const double c = -2.0 / occ, s1 = occ / (var_tau + occ), s2 = var_tau / (var_tau + occ);
+      for (int d = 0; d < D; ++d) {
+        double v = acc.variance_accumulator()[(size_t)i * D + d] / occ;
+        v = v + mu[d] * mu[d];
+        v = v + acc.mean_accumulator()[(size_t)i * D + d] * mu[d] * c;
+        v *= s1;
+        v += var[d] * s2;
+        var[d] = v;
+      }
+    }
+  }
+  // DiagGmmNormal::CopyToDiagGmm(gmm, flags) (csrc/diag-gmm-normal.cc:22-48)
+  if (flags & kGmmWeights) for (int g = 0; g < G; ++g) gmm->mutable_weights()[(size_t)g] = (float)w[(size_t)g];
+  if (flags & kGmmVariances) {
+    for (size_t i = 0; i < vars.size(); ++i) gmm->mutable_inv_vars()[i] = (float)(1.0 / vars[i]);
+    if (!(flags & kGmmMeans)) for (size_t i = 0; i < vars.size(); ++i) gmm->mutable_means_invvars()[i] = (float)old_means[i] * gmm->inv_vars()[i];
+  }
+  if (flags & kGmmMeans) for (size_t i = 0; i < means.size(); ++i) gmm->mutable_means_invvars()[i] = (float)means[i] * gmm->inv_vars()[i];
+  gmm->ComputeGconsts();
+  const float obj_new = MlObjective(*gmm, acc);
+  return {obj_new - obj_old, (float)occ_sum};
+}
+
+std::pair<float, float> MapAmDiagGmmUpdate(const MapDiagGmmOptions& cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm* am) {
+  KHG_REQUIRE(am != nullptr && acc.Dim() == am->Dim() && acc.NumAccs() == am->NumPdfs(),
+              "am_gmm != nullptr && am_diag_gmm_acc.Dim() == am_gmm->Dim() && am_diag_gmm_acc.NumAccs() == am_gmm->NumPdfs() assertion failed");
+  float obj = 0.0f, count = 0.0f;
+  for (int i = 0; i < acc.NumAccs(); ++i) {
+    const std::pair<float, float> r = MapDiagGmmUpdate(cfg, *acc.Acc(i), flags, am->GetPdf(i).get());
+    obj += r.first;
+    count += r.second;
+  }
+  return {obj, count};
+}
+
 // ---- AccumAmDiagGmm ---------------------------------------------------------------------------------------------------
 void AccumAmDiagGmm::Init(const AmDiagGmm& model, int dim, int flags) {
   accs_.clear();

@@ -176,6 +176,11 @@ struct MleDiagGmmOptions {
   std::string ToString() const;
 };
 
+struct MapDiagGmmOptions {      // csrc/mle-diag-gmm.h:47-66
+  float mean_tau = 10.0f, variance_tau = 50.0f, weight_tau = 10.0f;
+  std::string ToString() const;
+};
+
 // ---- csrc/mle-diag-gmm.h:68-181 ----------------------------------------------------------------------------------------
 class AccumDiagGmm {
  public:
@@ -216,6 +221,9 @@ MleUpdateResult MleFlatUpdate(const MleDiagGmmOptions& cfg, int P, int D, const 
                               const double* var_acc, int acc_flags, int flags, std::vector<float>* w, std::vector<float>* gc,
                               std::vector<float>* miv, std::vector<float>* iv, std::vector<int32_t>* new_off);
 float MlObjective(const DiagGmm& gmm, const AccumDiagGmm& acc);   // :479-499
+// MAP re-estimation with per-quantity smoothing counts (csrc/mle-diag-gmm.cc:392-477) -> (objf_change, count); runs on the host in
+// fp64 like the reference (a speaker-adaptation-sized update: not on the EM hot path)
+std::pair<float, float> MapDiagGmmUpdate(const MapDiagGmmOptions& cfg, const AccumDiagGmm& acc, int flags, DiagGmm* gmm);
 
 // ---- csrc/mle-am-diag-gmm.h:18-97 --------------------------------------------------------------------------------------
 class AccumAmDiagGmm {
@@ -252,5 +260,7 @@ class AccumAmDiagGmm {
 
 // csrc/mle-am-diag-gmm.cc:153-202 -> (objf_change, count); am_gmm updated in place
 MleUpdateResult MleAmDiagGmmUpdate(const MleDiagGmmOptions& cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm* am_gmm);
+// csrc/mle-am-diag-gmm.cc:204-227: MapDiagGmmUpdate pdf by pdf, the float sums of its two outputs
+std::pair<float, float> MapAmDiagGmmUpdate(const MapDiagGmmOptions& cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm* am_gmm);
 
 }  // namespace khg

@@ -72,7 +72,20 @@ struct MleTransitionUpdateConfig {    // csrc/transition-model.h:80-92
   bool share_for_pdfs = false;
 };
 
-class TransitionModel {
+class TransitionInformation {      // csrc/transition-information.h:26-77
+ public:
+  virtual ~TransitionInformation() = default;
+  virtual bool TransitionIdsEquivalent(int trans_id1, int trans_id2) const = 0;
+  virtual bool TransitionIdIsStartOfPhone(int trans_id) const = 0;
+  virtual int TransitionIdToPhone(int trans_id) const = 0;
+  virtual bool IsFinal(int trans_id) const = 0;
+  virtual bool IsSelfLoop(int trans_id) const = 0;
+  virtual int TransitionIdToPdf(int trans_id) const = 0;
+  virtual const std::vector<int>& TransitionIdToPdfArray() const = 0;
+  virtual int NumPdfs() const = 0;
+};
+
+class TransitionModel : public TransitionInformation {
  public:
   TransitionModel() = default;
   // pdf_info[pdf] = [(phone, pdf_class)] from ContextDependency::GetPdfInfo (csrc/context-dep.cc); csrc/transition-model.cc:120-252,
@@ -86,7 +99,8 @@ class TransitionModel {
   void Check() const;
   int NumTransitionIds() const { return (int)id2state_.size() - 1; }
   int NumTransitionStates() const { return (int)tuples_.size(); }
-  int NumPdfs() const { return num_pdfs_; }
+  int NumPdfs() const override { return num_pdfs_; }
+  const std::vector<int>& TransitionIdToPdfArray() const override { return id2pdf_; }
   const std::shared_ptr<HmmTopology>& topo() const { return topo_; }
   const std::vector<TransitionModelTuple>& tuples() const { return tuples_; }
   const std::vector<int>& state2id() const { return state2id_; }
@@ -95,14 +109,14 @@ class TransitionModel {
   const std::vector<float>& log_probs() const { return log_probs_; }
   const std::vector<float>& non_self_loop_log_probs() const { return nsl_; }
   void ChkTid(int tid) const { KHG_REQUIRE(tid > 0 && tid <= NumTransitionIds(), "transition-id " + std::to_string(tid) + " out of range"); }
-  int TransitionIdToPdf(int tid) const { ChkTid(tid); return id2pdf_[(size_t)tid]; }
-  int TransitionIdToPhone(int tid) const { ChkTid(tid); return tuples_[(size_t)id2state_[(size_t)tid] - 1].phone; }
+  int TransitionIdToPdf(int tid) const override { ChkTid(tid); return id2pdf_[(size_t)tid]; }
+  int TransitionIdToPhone(int tid) const override { ChkTid(tid); return tuples_[(size_t)id2state_[(size_t)tid] - 1].phone; }
   int TransitionIdToHmmState(int tid) const { ChkTid(tid); return tuples_[(size_t)id2state_[(size_t)tid] - 1].hmm_state; }
-  bool TransitionIdsEquivalent(int a, int b) const { ChkTid(a); ChkTid(b); return id2state_[(size_t)a] == id2state_[(size_t)b]; }
-  bool TransitionIdIsStartOfPhone(int tid) const { return TransitionIdToHmmState(tid) == 0; }
-  bool IsSelfLoop(int tid) const { ChkTid(tid); return IsSelfLoopRaw(tid); }
+  bool TransitionIdsEquivalent(int a, int b) const override { ChkTid(a); ChkTid(b); return id2state_[(size_t)a] == id2state_[(size_t)b]; }
+  bool TransitionIdIsStartOfPhone(int tid) const override { return TransitionIdToHmmState(tid) == 0; }
+  bool IsSelfLoop(int tid) const override { ChkTid(tid); return IsSelfLoopRaw(tid); }
   bool IsSelfLoopRaw(int tid) const;
-  bool IsFinal(int tid) const;
+  bool IsFinal(int tid) const override;
   int SelfLoopOf(int trans_state) const;
   float GetTransitionLogProb(int tid) const { KHG_REQUIRE(tid >= 0 && tid <= NumTransitionIds(), "transition-id out of range"); return log_probs_[(size_t)tid]; }
   int TupleToTransitionState(int phone, int hmm_state, int pdf, int self_loop_pdf) const;      // :432-447

@@ -32,6 +32,16 @@ GraphsCsr CsrFromDict(py::dict g) {
   c.weight = ToVec<float>(g["weight"]); c.final_w = ToVec<float>(g["final"]);
   return c;
 }
+// python/csrc/decodable-itf.cc:14-53: a decodable written in Python overrides these four
+class PyDecodableInterface : public DecodableInterface {
+ public:
+  using DecodableInterface::DecodableInterface;
+  float LogLikelihood(int frame, int index) const override { PYBIND11_OVERRIDE_PURE_NAME(float, DecodableInterface, "log_likelihood", LogLikelihood, frame, index); }
+  bool IsLastFrame(int frame) const override { PYBIND11_OVERRIDE_PURE_NAME(bool, DecodableInterface, "is_last_frame", IsLastFrame, frame); }
+  int NumFramesReady() const override { PYBIND11_OVERRIDE_NAME(int, DecodableInterface, "num_frames_ready", NumFramesReady); }
+  int NumIndices() const override { PYBIND11_OVERRIDE_PURE_NAME(int, DecodableInterface, "num_indices", NumIndices); }
+};
+
 py::object FstModule() { return py::module_::import("kaldi_hmm_gmm_amd.fst"); }
 
 AlignConfig ConfigFrom(py::object o) {
@@ -135,7 +145,14 @@ void BindAlign(py::module_& m) {
       .def_readwrite("hash_ratio", &FasterDecoderOptions::hash_ratio)
       .def("__str__", &FasterDecoderOptions::ToString);
 
-  py::class_<DecodableAmDiagGmmUnmapped, std::shared_ptr<DecodableAmDiagGmmUnmapped>>(m, "DecodableAmDiagGmmUnmapped")
+  py::class_<DecodableInterface, PyDecodableInterface, std::shared_ptr<DecodableInterface>>(m, "DecodableInterface")
+      .def(py::init<>())
+      .def("log_likelihood", &DecodableInterface::LogLikelihood, py::arg("frame"), py::arg("index"))
+      .def("is_last_frame", &DecodableInterface::IsLastFrame, py::arg("frame"))
+      .def("num_frames_ready", &DecodableInterface::NumFramesReady)
+      .def("num_indices", &DecodableInterface::NumIndices);
+
+  py::class_<DecodableAmDiagGmmUnmapped, DecodableInterface, std::shared_ptr<DecodableAmDiagGmmUnmapped>>(m, "DecodableAmDiagGmmUnmapped")
       .def(py::init([](std::shared_ptr<AmDiagGmm> am, Arr<float> feats, float) {
              if (feats.ndim() != 2) throw Error("feats must be a 2-D float matrix");
              return std::make_shared<DecodableAmDiagGmmUnmapped>(std::move(am), feats.data(), (int64_t)feats.shape(0), (int)feats.shape(1));

@@ -102,7 +102,17 @@ void BindHmm(py::module_& m) {
       .def(py::pickle([](const TransitionModelTuple& t) { return py::make_tuple(t.phone, t.hmm_state, t.forward_pdf, t.self_loop_pdf); },
                       [](py::tuple t) { return TransitionModelTuple{t[0].cast<int>(), t[1].cast<int>(), t[2].cast<int>(), t[3].cast<int>()}; }));
 
-  py::class_<TransitionModel, std::shared_ptr<TransitionModel>>(m, "TransitionModel")
+  py::class_<TransitionInformation, std::shared_ptr<TransitionInformation>>(m, "TransitionInformation")      // python/csrc/transition-information.cc:11-27
+      .def("transition_ids_equivalent", &TransitionInformation::TransitionIdsEquivalent, py::arg("trans_id1"), py::arg("trans_id2"))
+      .def("transition_ids_is_start_of_phone", &TransitionInformation::TransitionIdIsStartOfPhone, py::arg("trans_id"))
+      .def("transition_id_to_phone", &TransitionInformation::TransitionIdToPhone, py::arg("trans_id"))
+      .def("is_final", &TransitionInformation::IsFinal, py::arg("trans_id"))
+      .def("is_self_loop", &TransitionInformation::IsSelfLoop, py::arg("trans_id"))
+      .def("transition_id_to_pdf", &TransitionInformation::TransitionIdToPdf, py::arg("trans_id"))
+      .def("transition_id_to_pdf_array", [](TransitionInformation& t) { return t.TransitionIdToPdfArray(); })
+      .def_property_readonly("num_pdfs", &TransitionInformation::NumPdfs);
+
+  py::class_<TransitionModel, TransitionInformation, std::shared_ptr<TransitionModel>>(m, "TransitionModel")
       .def(py::init([](py::object ctx_dep, py::object hmm_topo) {
              if (ctx_dep.is_none()) {
                auto tm = std::make_shared<TransitionModel>();

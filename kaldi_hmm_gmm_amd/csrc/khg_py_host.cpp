@@ -271,6 +271,14 @@ void BindGmm(py::module_& m) {
                     })
       .def("__str__", &MleDiagGmmOptions::ToString);
 
+  py::class_<MapDiagGmmOptions>(m, "MapDiagGmmOptions")      // python/csrc/mle-diag-gmm.cc:40-58
+      .def(py::init([](float mt, float vt, float wt) { MapDiagGmmOptions o; o.mean_tau = mt; o.variance_tau = vt; o.weight_tau = wt; return o; }),
+           py::arg("mean_tau") = 10.0f, py::arg("variance_tau") = 50.0f, py::arg("weight_tau") = 10.0f)
+      .def_readwrite("mean_tau", &MapDiagGmmOptions::mean_tau)
+      .def_readwrite("variance_tau", &MapDiagGmmOptions::variance_tau)
+      .def_readwrite("weight_tau", &MapDiagGmmOptions::weight_tau)
+      .def("__str__", &MapDiagGmmOptions::ToString);
+
   py::class_<AccumDiagGmm, std::shared_ptr<AccumDiagGmm>>(m, "AccumDiagGmm")
       .def(py::init([](py::object gmm, int flags) {
              auto a = std::make_shared<AccumDiagGmm>();
@@ -327,6 +335,8 @@ void BindGmm(py::module_& m) {
   m.def("mle_diag_gmm_update", [](py::object cfg, const AccumDiagGmm& acc, int flags, DiagGmm& gmm) { return UpdateTuple(MleDiagGmmUpdate(OptsFrom(cfg), acc, flags, &gmm)); },
         py::arg("config"), py::arg("diag_gmm_acc"), py::arg("flags"), py::arg("gmm"));
   m.def("ml_objective", &MlObjective, py::arg("gmm"), py::arg("diaggmm_acc"));
+  m.def("map_diag_gmm_update", [](const MapDiagGmmOptions& cfg, const AccumDiagGmm& acc, int flags, DiagGmm& gmm) { return MapDiagGmmUpdate(cfg, acc, flags, &gmm); },
+        py::arg("config"), py::arg("diag_gmm_acc"), py::arg("flags"), py::arg("gmm"));
   // the flat M-step both updates go through: -> (new_off, w, gc, miv, iv, objf_change, count, floored_elements, floored_gaussians, removed)
   m.def("flat_update", [](py::object opts, Arr<int32_t> go, Arr<double> occ, py::object mean_acc, py::object var_acc, int acc_flags, int flags, Arr<float> w,
                           Arr<float> miv, Arr<float> iv) {
@@ -383,6 +393,8 @@ void BindGmm(py::module_& m) {
         a.AddDeviceStats(go.data(), occ.data(), ma.data(), va.data(), (int)ma.shape(1), st["total_frames"].cast<double>(), st["total_log_like"].cast<double>());
       }, py::arg("st"), py::arg("gauss_off"));
 
+  m.def("map_am_diag_gmm_update", [](const MapDiagGmmOptions& cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm& am) { return MapAmDiagGmmUpdate(cfg, acc, flags, &am); },
+        py::arg("config"), py::arg("amdiag_gmm_acc"), py::arg("flags"), py::arg("am_gmm"));
   m.def("mle_am_diag_gmm_update", [](py::object cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm& am) {
     const MleUpdateResult r = MleAmDiagGmmUpdate(OptsFrom(cfg), acc, flags, &am);
     return py::make_tuple(r.objf_change, r.count);

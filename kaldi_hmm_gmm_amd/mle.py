@@ -16,6 +16,7 @@ from .diag_gmm import AmDiagGmm
 AccumAmDiagGmm = _ext.AccumAmDiagGmm
 AccumDiagGmm = _ext.AccumDiagGmm
 MleDiagGmmOptions = _ext.MleDiagGmmOptions
+MapDiagGmmOptions = _ext.MapDiagGmmOptions
 ml_objective = _ext.ml_objective
 
 
@@ -58,6 +59,16 @@ def _flat_update(opts, gauss_off, occ, mean_acc, var_acc, acc_flags, flags, w, m
 def mle_diag_gmm_update(config, diag_gmm_acc, flags, gmm):
     """csrc/mle-diag-gmm.cc:243-390 -> (objf_change, count, floored_elements, floored_gaussians, removed)."""
     return _ext.mle_diag_gmm_update(config, diag_gmm_acc, int(flags), gmm)
+
+
+def map_diag_gmm_update(config, diag_gmm_acc, flags, gmm):
+    """csrc/mle-diag-gmm.cc:392-477 -> (objf_change, count)."""
+    return _ext.map_diag_gmm_update(config, diag_gmm_acc, int(flags), gmm)
+
+
+def map_am_diag_gmm_update(config, amdiag_gmm_acc, flags, am_gmm):
+    """csrc/mle-am-diag-gmm.cc:204-227 -> (objf_change, count)."""
+    return _ext.map_am_diag_gmm_update(config, amdiag_gmm_acc, int(flags), am_gmm)
 
 
 def mle_am_diag_gmm_update(config, amdiag_gmm_acc, flags, am_gmm):

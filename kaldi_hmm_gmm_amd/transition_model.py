@@ -6,8 +6,8 @@ binary), attached to the C++ class."""
 import numpy as np
 
 from . import device  # noqa: F401
-from ._kaldi_hmm_gmm_amd import (MleTransitionUpdateConfig, TransitionModel, TransitionModelTuple,  # noqa: F401
-                                 get_pdfs_for_phones)
+from ._kaldi_hmm_gmm_amd import (MleTransitionUpdateConfig, TransitionInformation, TransitionModel,  # noqa: F401
+                                 TransitionModelTuple, get_pdfs_for_phones)
 from ._lib import KhgError
 from .hmm_topology import HmmTopology
 

@@ -367,6 +367,47 @@ def mle_diag_gmm_update(weights, means_invvars, inv_vars, occ, mean_acc, var_acc
             "count": cnt.value, "floored_elems": fe.value, "floored_gauss": fg.value, "removed": rm.value}
 
 
+def map_diag_gmm_update(weights, means_invvars, inv_vars, occ, mean_acc, var_acc, flags=0x7, mean_tau=10.0, variance_tau=50.0,
+                        weight_tau=10.0):
+    """MapDiagGmmUpdate (csrc/mle-diag-gmm.cc:392-477) with DiagGmmNormal (csrc/diag-gmm-normal.cc:14-48) restated over arrays, one
+    numpy fp64 statement per statement of the reference; taus are the reference's floats widened.  -> new (weights, means_invvars,
+    inv_vars, gconsts, count).  (Test infrastructure; parity unpinned: the reference's tests hold no MAP answer, only the options'
+    defaults, python/tests/test_mle_diag_gmm.py:34-46.)"""
+    w32 = np.array(weights, f32, copy=True); miv32 = np.array(means_invvars, f32, copy=True); iv32 = np.array(inv_vars, f32, copy=True)
+    occ = np.asarray(occ, np.float64); ma = np.asarray(mean_acc, np.float64); va = np.asarray(var_acc, np.float64)
+    mean_tau, variance_tau, weight_tau = float(f32(mean_tau)), float(f32(variance_tau)), float(f32(weight_tau))
+    occ_sum = 0.0
+    for o in occ:
+        occ_sum += float(o)
+    w = w32.astype(np.float64); vars_ = 1.0 / iv32.astype(np.float64); means = miv32.astype(np.float64) * vars_
+    old_means = means.copy()
+    for i in range(w.shape[0]):
+        o = float(occ[i])
+        w[i] = (o + w[i] * weight_tau) / (occ_sum + weight_tau)
+        if o > 0.0 and flags & 1:
+            mean = ma[i] * (1.0 / (o + mean_tau))
+            mean = mean + means[i] * (mean_tau / (o + mean_tau))
+            means[i] = mean
+        if o > 0.0 and flags & 2:
+            old_var = vars_[i].copy()
+            var = va[i] / o
+            var = var + means[i] * means[i]
+            var = var + ma[i] * means[i] * (-2.0 / o)
+            var = var * (o / (variance_tau + o))
+            var = var + old_var * (variance_tau / (variance_tau + o))
+            vars_[i] = var
+    if flags & 4:
+        w32 = w.astype(f32)
+    if flags & 2:
+        iv32 = (1.0 / vars_).astype(f32)
+        if not flags & 1:
+            miv32 = (old_means.astype(f32) * iv32).astype(f32)
+    if flags & 1:
+        miv32 = (means.astype(f32) * iv32).astype(f32)
+    gc, _ = compute_gconsts(w32, iv32, miv32)
+    return {"weights": w32, "means_invvars": miv32, "inv_vars": iv32, "gconsts": gc, "count": float(f32(occ_sum))}
+
+
 def transition_mle_update(state2id, self_loop_of, stats, log_probs, nsl, floor=0.01, mincount=5.0):
     s2i = np.ascontiguousarray(state2id, np.int32); slo = np.ascontiguousarray(self_loop_of, np.int32)
     st = np.ascontiguousarray(stats, np.float64); lp = np.array(log_probs, f32, copy=True); ns = np.array(nsl, f32, copy=True)

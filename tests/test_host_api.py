@@ -632,3 +632,56 @@ def test_transition_mle_update_shared_for_pdfs():
         if n > 1:
             pooled = sum(stats[s2i[ts]: s2i[ts] + n] for ts in v)
             np.testing.assert_allclose(np.exp(tm_t.log_probs[s2i[v[0]]: s2i[v[0]] + n]), pooled / pooled.sum(), rtol=1e-6)
+
+
+def test_map_update_vs_oracle_and_reference_option_tests():
+    """MapDiagGmmOptions as the reference's own tests pin it (python/tests/test_mle_diag_gmm.py:34-46), and map_diag_gmm_update /
+    map_am_diag_gmm_update (csrc/mle-diag-gmm.cc:392-477, csrc/mle-am-diag-gmm.cc:204-227; python/csrc/mle-diag-gmm.cc:136-151) against
+    the oracle's numpy restatement: parameters bit for bit for every flag combination, zero-occupancy components left at their
+    prior, the objective change positive on statistics drawn away from the model."""
+    opts = khg.MapDiagGmmOptions()
+    assert abs(opts.mean_tau - 10) < 1e-5 and abs(opts.variance_tau - 50) < 1e-5 and abs(opts.weight_tau - 10) < 1e-5
+    opts = khg.MapDiagGmmOptions(mean_tau=1, variance_tau=2, weight_tau=3)
+    assert abs(opts.mean_tau - 1) < 1e-5 and abs(opts.variance_tau - 2) < 1e-5 and abs(opts.weight_tau - 3) < 1e-5
+    assert str(opts) == "MapDiagGmmOptions(mean_tau=1, variance_tau=2, weight_tau=3)"
+    rng = np.random.default_rng(12)
+    am = _rand_am(rng, 4, 6, 7)
+    accs = khg.AccumAmDiagGmm(); accs.init(am, khg.GmmUpdateFlags.kGmmAll)
+    for p in range(am.num_pdfs):
+        g, a = am.get_pdf(p), accs._accs[p]
+        occ = rng.uniform(0.0, 40.0, g.num_gauss)
+        occ[0] = 0.0                                    # no data: the component keeps its mean and variance
+        mu = g.means.astype(np.float64) + rng.normal(0, 0.5, g.means.shape)
+        var = g.vars.astype(np.float64) * rng.uniform(0.5, 2.0, g.vars.shape)
+        a.occupancy[:] = occ
+        a.mean_accumulator[:] = occ[:, None] * mu
+        a.variance_accumulator[:] = occ[:, None] * (var + mu * mu)
+    cfg = khg.MapDiagGmmOptions(mean_tau=4.0, variance_tau=20.0, weight_tau=8.0)
+    for flags in ("mvw", "mw", "vw", "w", "mv", "m"):
+        f = khg.str_to_gmm_flags(flags)
+        am2 = khg.AmDiagGmm(); am2.copy_from_am_diag_gmm(am)
+        tot_obj, tot_cnt = np.float32(0), np.float32(0)
+        for p in range(am.num_pdfs):
+            g = khg.DiagGmm(gmm=am.get_pdf(p))
+            a = accs.get_acc(p)
+            want = orc.map_diag_gmm_update(g.weights, g.means_invvars, g.inv_vars, a.occupancy, a.mean_accumulator, a.variance_accumulator,
+                                           flags=int(f), mean_tau=4.0, variance_tau=20.0, weight_tau=8.0)
+            before = (g.weights, g.means_invvars, g.inv_vars)
+            obj, cnt = khg.map_diag_gmm_update(cfg, a, f, g)
+            np.testing.assert_array_equal(g.weights, want["weights"]); np.testing.assert_array_equal(g.inv_vars, want["inv_vars"])
+            np.testing.assert_array_equal(g.means_invvars, want["means_invvars"]); np.testing.assert_array_equal(g.gconsts, want["gconsts"])
+            assert cnt == want["count"] and g.valid_gconsts
+            if not int(f) & 4:
+                np.testing.assert_array_equal(g.weights, before[0])
+            if not int(f) & 2:
+                np.testing.assert_array_equal(g.inv_vars, before[2])
+            if int(f) & 1 and not int(f) & 2:
+                np.testing.assert_array_equal(g.means[0], am.get_pdf(p).means[0])      # occ = 0: the prior mean
+            if flags == "mvw":
+                assert obj > 0
+            tot_obj = np.float32(tot_obj + np.float32(obj)); tot_cnt = np.float32(tot_cnt + np.float32(cnt))
+        obj_am, cnt_am = khg.map_am_diag_gmm_update(cfg, accs, f, am2)
+        assert obj_am == float(tot_obj) and cnt_am == float(tot_cnt)
+    with pytest.raises(khg.KhgError, match="Flags in argument do not match"):
+        a = khg.AccumDiagGmm(am.get_pdf(0), khg.GmmUpdateFlags.kGmmWeights)
+        khg.map_diag_gmm_update(cfg, a, khg.GmmUpdateFlags.kGmmAll & 7, khg.DiagGmm(gmm=am.get_pdf(0)))
