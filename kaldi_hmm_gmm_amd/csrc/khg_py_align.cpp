@@ -1,11 +1,11 @@
-// pybind11 bindings of the alignment API (khg_host_align.hpp) with the names of python/csrc/{decoder-wrappers,faster-decoder,
-// decodable-am-diag-gmm}.cc in /root/reference/kaldi-hmm-gmm.  The graph container (the reference's kaldifst VectorFst) is the
-// Python StdVectorFst: the two places that need it (ModifyGraphForCarefulAlignment, the CSR view) call its module.
+// pybind11 bindings of the alignment API (khg_host_align.hpp, khg_host_fst.hpp) with the names of python/csrc/{decoder-wrappers,
+// faster-decoder,decodable-am-diag-gmm,decodable-itf,hmm-utils}.cc in /root/reference/kaldi-hmm-gmm, and of the graph container with
+// the kaldifst method names the reference's scripts use (StdVectorFst, StdArc).
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
-#include "khg_host_align.hpp"
+#include "khg_host_fst.hpp"
 
 namespace py = pybind11;
 using namespace khg;
@@ -20,18 +20,14 @@ Arr<T> Vec1(const std::vector<T>& v) {
   if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), sizeof(T) * v.size());
   return a;
 }
-template <class T>
-std::vector<T> ToVec(py::handle o) {
-  Arr<T> a = o.cast<Arr<T>>();
-  return std::vector<T>(a.data(), a.data() + a.size());
+py::dict CsrToDict(const GraphsCsr& c) {
+  py::dict d;
+  d["state_off"] = Vec1(c.state_off); d["arc_off"] = Vec1(c.arc_off); d["start"] = Vec1(c.start);
+  d["ilabel"] = Vec1(c.ilabel); d["olabel"] = Vec1(c.olabel); d["nextstate"] = Vec1(c.nextstate);
+  d["weight"] = Vec1(c.weight); d["final"] = Vec1(c.final_w);
+  return d;
 }
-GraphsCsr CsrFromDict(py::dict g) {
-  GraphsCsr c;
-  c.state_off = ToVec<int64_t>(g["state_off"]); c.arc_off = ToVec<int64_t>(g["arc_off"]); c.start = ToVec<int32_t>(g["start"]);
-  c.ilabel = ToVec<int32_t>(g["ilabel"]); c.olabel = ToVec<int32_t>(g["olabel"]); c.nextstate = ToVec<int32_t>(g["nextstate"]);
-  c.weight = ToVec<float>(g["weight"]); c.final_w = ToVec<float>(g["final"]);
-  return c;
-}
+
 // python/csrc/decodable-itf.cc:14-53: a decodable written in Python overrides these four
 class PyDecodableInterface : public DecodableInterface {
  public:
@@ -42,13 +38,18 @@ class PyDecodableInterface : public DecodableInterface {
   int NumIndices() const override { PYBIND11_OVERRIDE_PURE_NAME(int, DecodableInterface, "num_indices", NumIndices); }
 };
 
-py::object FstModule() { return py::module_::import("kaldi_hmm_gmm_amd.fst"); }
-
 AlignConfig ConfigFrom(py::object o) {
   if (py::isinstance<AlignConfig>(o)) return o.cast<AlignConfig>();
   AlignConfig c;
   c.beam = o.attr("beam").cast<float>(); c.retry_beam = o.attr("retry_beam").cast<float>(); c.careful = o.attr("careful").cast<bool>();
   return c;
+}
+void CheckBeams(const AlignConfig& cfg) {      // csrc/decoder-wrappers.cc:29-33
+  if ((cfg.retry_beam != 0 && cfg.retry_beam <= cfg.beam) || cfg.beam <= 0.0f) {
+    char b[128];
+    std::snprintf(b, sizeof(b), "Beams do not make sense: beam %g, retry-beam %g", (double)cfg.beam, (double)cfg.retry_beam);
+    throw Error(b);
+  }
 }
 
 py::list ResultsToList(const std::vector<AlignResult>& rs, const std::vector<int64_t>& nframes, bool return_scores) {
@@ -72,25 +73,23 @@ py::list ResultsToList(const std::vector<AlignResult>& rs, const std::vector<int
 }
 
 // align_batch(am, tm, fsts, feats_list, config, acoustic_scale, trans_cost=None, decoder_opts=None, return_scores=False)
-py::list AlignBatchPy(std::shared_ptr<AmDiagGmm> am, std::shared_ptr<TransitionModel> tm, py::list fsts, py::list feats_list, py::object config,
-                      float acoustic_scale, py::object trans_cost, py::object decoder_opts, bool return_scores) {
+py::list AlignBatchPy(std::shared_ptr<AmDiagGmm> am, std::shared_ptr<TransitionModel> tm, std::vector<std::shared_ptr<StdVectorFst>> fsts, py::list feats_list,
+                      py::object config, float acoustic_scale, py::object trans_cost, py::object decoder_opts, bool return_scores) {
   const AlignConfig cfg = ConfigFrom(config);
-  if ((cfg.retry_beam != 0 && cfg.retry_beam <= cfg.beam) || cfg.beam <= 0.0f) {
-    char b[128];
-    std::snprintf(b, sizeof(b), "Beams do not make sense: beam %g, retry-beam %g", (double)cfg.beam, (double)cfg.retry_beam);
-    throw Error(b);
-  }
-  py::object fstmod = FstModule();
-  py::list graphs = fsts;
-  if (cfg.careful) {                       // on copies: the batch entry point leaves the caller's graphs alone
-    graphs = py::list();
-    for (py::handle f : fsts) {
-      py::object c = f.attr("copy")();
-      if (c.attr("start").cast<int>() != -1) fstmod.attr("modify_graph_for_careful_alignment")(c);
-      graphs.append(c);
+  CheckBeams(cfg);
+  std::vector<StdVectorFst> careful;           // on copies: the batch entry point leaves the caller's graphs alone
+  std::vector<const StdVectorFst*> gp;
+  if (cfg.careful) {
+    careful.reserve(fsts.size());
+    for (auto& f : fsts) {
+      careful.push_back(*f);
+      if (careful.back().Start() != kNoStateId) ModifyGraphForCarefulAlignment(&careful.back());
     }
+    for (auto& f : careful) gp.push_back(&f);
+  } else {
+    for (auto& f : fsts) gp.push_back(f.get());
   }
-  const GraphsCsr csr = CsrFromDict(fstmod.attr("concat_graphs")(graphs).cast<py::dict>());
+  const GraphsCsr csr = ConcatGraphs(gp);
   const int D = am->Dim();
   std::vector<Arr<float>> keep;
   std::vector<const float*> fp;
@@ -183,24 +182,130 @@ void BindAlign(py::module_& m) {
 
   // python/csrc/decoder-wrappers.cc:25-47 -> (num_done, num_error, num_retried, tot_like, frame_count, alignment, words); the counters
   // are passed by value and returned incremented
-  m.def("align_utterance_wrapper", [](py::object config, const std::string&, float acoustic_scale, py::object fst, py::object decodable, int num_done,
-                                      int num_error, int num_retried, double tot_like, int64_t frame_count) {
+  m.def("align_utterance_wrapper", [](py::object config, const std::string&, float acoustic_scale, std::shared_ptr<StdVectorFst> fst, py::object decodable,
+                                      int num_done, int num_error, int num_retried, double tot_like, int64_t frame_count) {
     if (!py::isinstance<DecodableAmDiagGmmScaled>(decodable)) throw Error("align_utterance_wrapper: the HIP path needs a DecodableAmDiagGmmScaled");
     auto dec = decodable.cast<std::shared_ptr<DecodableAmDiagGmmScaled>>();
     // the reference scales scores by the decodable's scale and `like` by acoustic_scale; the scripts pass the same value
     if (dec->scale() != acoustic_scale) throw Error("align_utterance_wrapper: decodable scale and acoustic_scale must agree on this path");
     AlignConfig cfg = ConfigFrom(config);
-    if (cfg.careful && fst.attr("start").cast<int>() != -1) {
-      FstModule().attr("modify_graph_for_careful_alignment")(fst);      // the reference mutates the caller's fst (decoder-wrappers.cc:43-45)
+    CheckBeams(cfg);
+    if (cfg.careful && fst->Start() != kNoStateId) {
+      ModifyGraphForCarefulAlignment(fst.get());      // the reference mutates the caller's fst (decoder-wrappers.cc:43-45)
       cfg.careful = false;
     }
-    py::list fsts; fsts.append(fst);
-    py::list feats; feats.append(decodable.attr("_feats"));
-    py::dict r = AlignBatchPy(dec->am(), dec->tm(), fsts, feats, py::cast(cfg), acoustic_scale, py::none(), py::none(), false)[0].cast<py::dict>();
-    if (r["retried"].cast<bool>()) num_retried += 1;
-    if (!r["ok"].cast<bool>()) return py::tuple(py::make_tuple(num_done, num_error + 1, num_retried, tot_like, frame_count, py::list(), py::list()));
-    return py::tuple(py::make_tuple(num_done + 1, num_error, num_retried, tot_like + r["like"].cast<double>(), frame_count + r["num_frames"].cast<int64_t>(),
-                                    py::object(r["alignment"]), py::object(r["words"])));
+    AlignResult r;
+    {
+      py::gil_scoped_release nogil;
+      r = AlignBatch(*dec->am(), *dec->tm(), ConcatGraphs({fst.get()}), {dec->feats().data()}, {(int64_t)dec->NumFramesReady()}, cfg, acoustic_scale, nullptr,
+                     nullptr, false)[0];
+    }
+    if (r.retried) num_retried += 1;
+    if (!r.ok) return py::tuple(py::make_tuple(num_done, num_error + 1, num_retried, tot_like, frame_count, py::list(), py::list()));
+    return py::tuple(py::make_tuple(num_done + 1, num_error, num_retried, tot_like + (double)r.like, frame_count + (int64_t)r.num_frames, py::cast(r.alignment),
+                                    py::cast(r.words)));
   }, py::arg("config"), py::arg("utt"), py::arg("acoustic_scale"), py::arg("fst"), py::arg("decodable"), py::arg("num_done") = 0, py::arg("num_error") = 0,
      py::arg("num_retried") = 0, py::arg("tot_like") = 0.0, py::arg("frame_count") = 0);
+
+  // ---- the graph container (kaldifst's method names) -----------------------------------------------------------------------------
+  m.attr("kNoStateId") = kNoStateId;
+  py::class_<StdArc>(m, "StdArc")
+      .def(py::init([](int il, int ol, double w, int ns) { return StdArc{il, ol, (float)w, ns}; }), py::arg("ilabel"), py::arg("olabel"), py::arg("weight"),
+           py::arg("nextstate"))
+      .def_readwrite("ilabel", &StdArc::ilabel).def_readwrite("olabel", &StdArc::olabel).def_readwrite("nextstate", &StdArc::nextstate)
+      .def_property("weight", [](const StdArc& a) { return (double)a.weight; }, [](StdArc& a, double w) { a.weight = (float)w; })
+      .def("__repr__", &StdArc::ToString);
+
+  py::class_<StdVectorFst, std::shared_ptr<StdVectorFst>>(m, "StdVectorFst")
+      .def(py::init<>())
+      .def("add_state", &StdVectorFst::AddState)
+      .def_property_readonly("num_states", &StdVectorFst::NumStates)
+      .def_property("start", &StdVectorFst::Start, &StdVectorFst::SetStart)
+      .def("set_start", &StdVectorFst::SetStart)
+      .def("add_arc", [](StdVectorFst& f, int state, py::object arc, py::kwargs kw) {
+        if (!arc.is_none()) { f.AddArc(state, arc.cast<StdArc>()); return; }
+        f.AddArc(state, StdArc{kw["ilabel"].cast<int>(), kw["olabel"].cast<int>(), kw.contains("weight") ? (float)kw["weight"].cast<double>() : 0.0f,
+                               kw["nextstate"].cast<int>()});
+      }, py::arg("state"), py::arg("arc") = py::none())
+      .def("set_final", [](StdVectorFst& f, int s, double w) { f.SetFinal(s, (float)w); }, py::arg("state"), py::arg("weight") = 0.0)
+      .def("final", [](StdVectorFst& f, int s) { return (double)f.Final(s); }, py::arg("state"))
+      .def("is_final", &StdVectorFst::IsFinal, py::arg("state"))
+      .def("arcs", [](StdVectorFst& f, int s) { return f.Arcs(s); }, py::arg("state"))       // copies: the container owns its arcs
+      .def("num_arcs", [](StdVectorFst& f, py::object s) { return s.is_none() ? f.NumArcs() : (int64_t)f.Arcs(s.cast<int>()).size(); }, py::arg("state") = py::none())
+      .def("copy", [](StdVectorFst& f) { return std::make_shared<StdVectorFst>(f); })
+      .def_property_readonly("_arcs", [](StdVectorFst& f) { return f.arcs(); })
+      .def_property_readonly("_final", [](StdVectorFst& f) { return std::vector<double>(f.finals().begin(), f.finals().end()); })
+      .def_property_readonly("_start", &StdVectorFst::Start)
+      .def("to_csr", [](StdVectorFst& f) {
+        const GraphsCsr c = ConcatGraphs({&f});
+        py::dict d;
+        d["start"] = f.Start(); d["arc_off"] = Vec1(c.arc_off); d["ilabel"] = Vec1(c.ilabel); d["olabel"] = Vec1(c.olabel); d["weight"] = Vec1(c.weight);
+        d["nextstate"] = Vec1(c.nextstate); d["final"] = Vec1(c.final_w);
+        return d;
+      })
+      .def_static("from_csr", [](int start, Arr<int64_t> arc_off, Arr<int32_t> il, Arr<int32_t> ol, Arr<float> w, Arr<int32_t> ns, Arr<float> fin) {
+        auto f = std::make_shared<StdVectorFst>();
+        for (py::ssize_t s = 0; s < fin.size(); ++s) {
+          f->AddState();
+          f->SetFinal((int)s, fin.at(s));
+          for (int64_t a = arc_off.at(s); a < arc_off.at(s + 1); ++a) f->AddArc((int)s, StdArc{il.at(a), ol.at(a), w.at(a), ns.at(a)});
+        }
+        f->SetStart(start);
+        return f;
+      }, py::arg("start"), py::arg("arc_off"), py::arg("ilabel"), py::arg("olabel"), py::arg("weight"), py::arg("nextstate"), py::arg("final"));
+
+  m.def("concat_graphs", [](std::vector<std::shared_ptr<StdVectorFst>> fsts) {
+    std::vector<const StdVectorFst*> p;
+    for (auto& f : fsts) p.push_back(f.get());
+    return CsrToDict(ConcatGraphs(p));
+  }, py::arg("fsts"));
+  m.def("modify_graph_for_careful_alignment", [](StdVectorFst& f) { ModifyGraphForCarefulAlignment(&f); }, py::arg("fst"));
+  // python/csrc/hmm-utils.cc:14-19: disambig_syms defaults to empty; the rest are required
+  m.def("add_transition_probs", [](const TransitionModel& tm, std::vector<int> disambig, py::object ts, py::object sl, py::object fst) {
+    if (ts.is_none() || sl.is_none() || fst.is_none()) throw py::type_error("add_transition_probs(): transition_scale, self_loop_scale and fst are required");
+    AddTransitionProbs(tm, disambig, ts.cast<float>(), sl.cast<float>(), fst.cast<std::shared_ptr<StdVectorFst>>().get());
+  }, py::arg("trans_model"), py::arg("disambig_syms") = std::vector<int>(), py::arg("transition_scale") = py::none(), py::arg("self_loop_scale") = py::none(),
+     py::arg("fst") = py::none());
+
+  py::class_<LatticeWeight>(m, "LatticeWeight")
+      .def(py::init([](double a, double b) { return LatticeWeight{a, b}; }), py::arg("value1") = 0.0, py::arg("value2") = 0.0)
+      .def_readwrite("value1", &LatticeWeight::value1).def_readwrite("value2", &LatticeWeight::value2)
+      .def("__repr__", [](const LatticeWeight& w) {
+        return "LatticeWeight(" + py::repr(py::float_(w.value1)).cast<std::string>() + ", " + py::repr(py::float_(w.value2)).cast<std::string>() + ")";
+      });
+  py::class_<LatticeArc>(m, "LatticeArc")
+      .def(py::init([](int il, int ol, LatticeWeight w, int ns) { return LatticeArc{il, ol, w, ns}; }), py::arg("ilabel"), py::arg("olabel"), py::arg("weight"),
+           py::arg("nextstate"))
+      .def_readwrite("ilabel", &LatticeArc::ilabel).def_readwrite("olabel", &LatticeArc::olabel).def_readwrite("weight", &LatticeArc::weight)
+      .def_readwrite("nextstate", &LatticeArc::nextstate);
+  py::class_<LinearLattice>(m, "LinearLattice")
+      .def(py::init<>())
+      .def_readwrite("arcs", &LinearLattice::arcs).def_readwrite("final", &LinearLattice::final_w).def_readwrite("start", &LinearLattice::start)
+      .def_property_readonly("num_states", &LinearLattice::NumStates)
+      .def("get_linear_symbol_sequence", [](const LinearLattice& l) {
+        std::vector<int> il, ol;
+        LatticeWeight w;
+        const bool ok = l.GetLinearSymbolSequence(&il, &ol, &w);
+        return py::make_tuple(ok, il, ol, w);
+      });
+
+  py::class_<FasterDecoder>(m, "FasterDecoder")      // python/csrc/faster-decoder.cc:33-53 (the method is spelled advanced_decoding there)
+      .def(py::init<std::shared_ptr<StdVectorFst>, const FasterDecoderOptions&>(), py::arg("fst"), py::arg("config"))
+      .def("set_options", &FasterDecoder::SetOptions, py::arg("config"))
+      .def("init_decoding", &FasterDecoder::InitDecoding)
+      .def("decode", [](FasterDecoder& d, py::object dec) {
+        if (!py::isinstance<DecodableAmDiagGmmScaled>(dec)) throw Error("FasterDecoder: the HIP path needs a DecodableAmDiagGmmScaled");
+        d.Decode(dec.cast<std::shared_ptr<DecodableAmDiagGmmScaled>>());
+      }, py::arg("decodable"))
+      .def("advanced_decoding", [](FasterDecoder& d, py::object dec, int max_num_frames) {
+        if (!py::isinstance<DecodableAmDiagGmmScaled>(dec)) throw Error("FasterDecoder: the HIP path needs a DecodableAmDiagGmmScaled");
+        d.AdvanceDecoding(dec.cast<std::shared_ptr<DecodableAmDiagGmmScaled>>(), max_num_frames);
+      }, py::arg("decodable"), py::arg("max_num_frames") = -1)
+      .def("num_frames_decoded", &FasterDecoder::NumFramesDecoded)
+      .def("reached_final", &FasterDecoder::ReachedFinal)
+      .def("get_best_path", [](FasterDecoder& d, bool use_final_probs) {
+        LinearLattice lat;
+        const bool ok = d.GetBestPath(&lat, use_final_probs);
+        return py::make_tuple(ok, lat);
+      }, py::arg("use_final_probs") = true);
 }

@@ -543,9 +543,11 @@ def test_pybind11_module_is_the_host_surface():
     # the reference-named host classes ARE the extension's C++ classes (csrc/khg_host_{gmm,hmm,align}.cpp), not Python mirrors
     for name in ("DiagGmm", "AmDiagGmm", "AccumDiagGmm", "AccumAmDiagGmm", "MleDiagGmmOptions", "HmmState", "HmmTopology",
                  "TransitionModelTuple", "TransitionModel", "MleTransitionUpdateConfig", "AlignConfig", "FasterDecoderOptions",
-                 "DecodableAmDiagGmmUnmapped", "DecodableAmDiagGmmScaled"):
+                 "DecodableAmDiagGmmUnmapped", "DecodableAmDiagGmmScaled", "DecodableInterface", "TransitionInformation", "MapDiagGmmOptions",
+                 "FasterDecoder", "LatticeWeight", "LatticeArc", "LinearLattice", "StdVectorFst", "StdArc"):
         assert getattr(khg, name) is getattr(ext, name), name
     assert khg.align_utterance_wrapper is ext.align_utterance_wrapper and khg.align_batch is ext.align_batch
+    assert khg.add_transition_probs is ext.add_transition_probs and khg.modify_graph_for_careful_alignment is ext.modify_graph_for_careful_alignment
     assert khg.get_pdfs_for_phones is ext.get_pdfs_for_phones and khg.ml_objective is ext.ml_objective
     for cls, methods in ((ext.DiagGmm, "resize set_weights set_means set_invvars compute_gconsts log_likelihood log_likelihoods component_posteriors "
                                        "split merge perturb generate interpolate remove_component"),
