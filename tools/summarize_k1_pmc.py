@@ -1,12 +1,12 @@
 """Per-launch averages of the K1 counters collected by tools/pmc_k1_r2.sh -> JSON on stdout."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 out = {}
 for sub in "abc":
     fs = glob.glob(f"{sys.argv[1]}/{sub}/*/*_counter_collection.csv")
     if not fs:
         continue
     d = {}
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):      # the newest run (files are named by pid)
         kn = r["Kernel_Name"]
         if kn.startswith(("void k1p_loglikes", "k1p_loglikes", "void k1_loglikes", "k1_loglikes", "void k1b_loglikes", "k1b_loglikes", "void k1h_loglikes", "k1h_loglikes", "void k1s_loglikes", "k1s_loglikes")):
             d.setdefault(kn.split("(")[0], {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)

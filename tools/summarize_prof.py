@@ -32,7 +32,7 @@ def one(pattern):
     f = glob.glob(os.path.join(SRC, pattern))
     if not f:
         raise SystemExit(f"missing {pattern} under {SRC}")
-    return f[0]
+    return max(f, key=os.path.getmtime)      # gpurun MERGES runs into gpurun_out/: rocprofv3 names files by pid, take the newest
 
 
 def counters(sub):
