@@ -1805,7 +1805,8 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
     const int k3form = ctx->opt[KHG_OPT_K3_FORM];     // 1: the chunk-per-block MFMA form for every shape; 2: the VALU form
-    const bool use_mfma = maxG <= 128 && k3form != 2 && m->KQ != 0;
+    // the chunk-per-block MFMA form holds 16 * 4 * NBW Gaussians: NBW <= 2 at D <= 80, <= 4 at D <= 40 (the accumulators are registers)
+    const bool use_mfma = (maxG <= 128 || (maxG <= 256 && m->KQ == 10)) && k3form != 2 && m->KQ != 0;
     const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && k3form != 1;
     if (use_wave) {
       // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
@@ -1875,7 +1876,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         {
           KernelTimer kt(ctx, "k3_accumulate");
           if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 128) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 192) hipLaunchKernelGGL((k3_accumulate_mfma<10, 3>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 4>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
           else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
           else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
         }

@@ -1,6 +1,6 @@
 """Shapes past the tile kernels' limits: feature dimensions 80 < D <= KHG_MAX_DIM run K1 on the vector ALUs
-(k1w_loglikes) and K3 in its any-dimension form (k3_accumulate<0>); pdfs of more than 128 Gaussians run the VALU K3 at any
-D.  The reference has no such limits (csrc/diag-gmm.h:243-256).  Same bounds as tests/test_gpu_parity.py: log-likes
+(k1w_loglikes) and K3 in its any-dimension form (k3_accumulate<0>); pdfs of more than 128 Gaussians run the MFMA block form of K3 up to 256 Gaussians at D <= 40
+and the VALU K3 otherwise.  The reference has no such limits (csrc/diag-gmm.h:243-256).  Same bounds as tests/test_gpu_parity.py: log-likes
 within 1e-5 + 1e-6 B max(1, D / 80) of the fp64 value (a sequential fp32 chain of 2 D terms: the bound of
 tests/test_gpu_parity.py was stated for 2 D <= 160 terms and grows with their number; the oracle's fp32 sums must meet it too), alignments identical to the oracle decoder's, statistics to 2e-5, the M-step's
 parameters bit-identical to the host form."""
@@ -26,7 +26,7 @@ def _device(ctx, m, gc, ut, cost, weights=False):
     return dm, tm, us
 
 
-@pytest.mark.parametrize("P,G,D,ragged", [(12, 16, 120, True), (9, 200, 40, True), (6, 150, 81, False), (5, 3, 257, True)])
+@pytest.mark.parametrize("P,G,D,ragged", [(12, 16, 120, True), (9, 200, 40, True), (5, 256, 39, False), (4, 260, 40, True), (6, 150, 81, False), (5, 3, 257, True)])
 def test_wide_loglikes_align_accstats_vs_oracle(ctx, P, G, D, ragged):
     from kaldi_hmm_gmm_amd import DeviceAccs
 
