@@ -292,6 +292,69 @@ double DiagGmm::ComponentPosteriors(const float* data, size_t n, std::vector<flo
   for (int g = 0; g < G_; ++g) (*post)[(size_t)g] = (float)st.occ[(size_t)g];
   return st.total_log_like;
 }
+namespace {
+// csrc/kaldi-math.h:59-78
+inline float LogAddF(float x, float y) {
+  static const float kMinLogDiffFloat = std::log(std::numeric_limits<float>::epsilon());
+  float diff;
+  if (x < y) { diff = x - y; x = y; } else { diff = y - x; }
+  if (diff >= kMinLogDiffFloat) return x + std::log1p(std::exp(diff));
+  return x;
+}
+// the selection step shared by the three forms: candidates (loglike, id), keep those >= the n-th largest, best first
+float SelectBest(const std::vector<float>& loglikes, const std::vector<int32_t>& ids, int keep, std::vector<int32_t>* output) {
+  const int n = (int)loglikes.size();
+  float thresh = -std::numeric_limits<float>::infinity();
+  if (keep < n) {
+    std::vector<float> c = loglikes;
+    std::nth_element(c.begin(), c.begin() + (n - keep), c.end());
+    thresh = c[(size_t)(n - keep)];
+  }
+  std::vector<std::pair<float, int32_t>> pairs;
+  for (int p = 0; p < n; ++p)
+    if (loglikes[(size_t)p] >= thresh) pairs.emplace_back(loglikes[(size_t)p], ids[(size_t)p]);
+  std::sort(pairs.begin(), pairs.end(), std::greater<std::pair<float, int32_t>>());
+  float tot = -std::numeric_limits<float>::infinity();
+  output->clear();
+  for (int j = 0; j < keep && j < (int)pairs.size(); ++j) {
+    output->push_back(pairs[(size_t)j].second);
+    tot = LogAddF(tot, pairs[(size_t)j].first);
+  }
+  KHG_REQUIRE(!output->empty(), "!output->empty() assertion failed");
+  return tot;
+}
+}  // namespace
+
+float DiagGmm::GaussianSelection(const float* data, size_t n, int num_gselect, std::vector<int32_t>* output) const {
+  const std::vector<float> ll = LogLikelihoods(data, n);
+  std::vector<int32_t> ids((size_t)G_);
+  for (int g = 0; g < G_; ++g) ids[(size_t)g] = g;
+  return SelectBest(ll, ids, num_gselect, output);
+}
+float DiagGmm::GaussianSelectionMatrix(const float* data, size_t rows, size_t cols, int num_gselect, std::vector<std::vector<int32_t>>* output) const {
+  KHG_REQUIRE(rows != 0, "num_frames != 0 assertion failed");
+  const std::vector<float> mat = LogLikelihoodsMatrix(data, rows, cols);      // [N][G]: one K1 launch for all frames
+  std::vector<int32_t> ids((size_t)G_);
+  for (int g = 0; g < G_; ++g) ids[(size_t)g] = g;
+  output->assign(rows, std::vector<int32_t>());
+  double ans = 0.0;
+  for (size_t t = 0; t < rows; ++t) {
+    const std::vector<float> ll(mat.begin() + t * G_, mat.begin() + (t + 1) * G_);
+    ans += SelectBest(ll, ids, num_gselect, &(*output)[t]);
+  }
+  return (float)ans;
+}
+float DiagGmm::GaussianSelectionPreselect(const float* data, size_t n, const std::vector<int32_t>& preselect, int num_gselect, std::vector<int32_t>* output) const {
+  KHG_REQUIRE(!preselect.empty(), "preselect is empty");
+  const std::vector<float> all = LogLikelihoods(data, n);
+  std::vector<float> ll;
+  for (int32_t g : preselect) {
+    KHG_REQUIRE(g >= 0 && g < G_, "preselect: component index out of range");
+    ll.push_back(all[(size_t)g]);
+  }
+  return SelectBest(ll, preselect, std::min(num_gselect, (int)preselect.size()), output);
+}
+
 void DiagGmm::Split(int target, float perturb_factor, std::vector<int>* history, const RandnFn& randn) {
   int cur = G_;
   KHG_REQUIRE(!(target < cur || cur == 0), "Cannot split from " + std::to_string(cur) + " to " + std::to_string(target) + " components");

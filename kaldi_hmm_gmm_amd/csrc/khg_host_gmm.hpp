@@ -120,6 +120,11 @@ class DiagGmm {
   std::vector<float> LogLikelihoods(const float* data, size_t n) const;                     // :167-176 -> [G]
   std::vector<float> LogLikelihoodsMatrix(const float* data, size_t rows, size_t cols) const;  // :177-189 -> [N][G]
   double ComponentPosteriors(const float* data, size_t n, std::vector<float>* post) const;  // :368-392, K3 -> log-like
+  // Gaussian selection (csrc/diag-gmm.cc:201-365): the num_gselect best components of a frame, best first, and the log-sum of
+  // their likelihoods (K1 for the scores, the selection itself on the host)
+  float GaussianSelection(const float* data, size_t n, int num_gselect, std::vector<int32_t>* output) const;
+  float GaussianSelectionMatrix(const float* data, size_t rows, size_t cols, int num_gselect, std::vector<std::vector<int32_t>>* output) const;
+  float GaussianSelectionPreselect(const float* data, size_t n, const std::vector<int32_t>& preselect, int num_gselect, std::vector<int32_t>* output) const;
   void Split(int target_components, float perturb_factor, std::vector<int>* history, const RandnFn& randn);   // :780-851
   std::vector<int> Merge(int target_components);               // :557-759 (khg_diag_gmm_merge) -> history
   void Perturb(float perturb_factor, const RandnFn& randn);    // :463-484

@@ -170,11 +170,30 @@ void BindGmm(py::module_& m) {
         const double ll = g.ComponentPosteriors(x.data(), (size_t)x.size(), &post);
         return py::make_tuple(ll, Vec1(post));
       })
+      // -> the split history like python/csrc/diag-gmm.cc:69-77 (new component i + old count was split off component history[i]);
+      // `history` (a list, extended too) and `randn` (the deviates, the reference draws them itself) are this package's additions
       .def("split", [](DiagGmm& g, int target, float perturb, py::object history, py::object randn) {
         std::vector<int> h;
-        g.Split(target, perturb, history.is_none() ? nullptr : &h, MakeRandn(randn));
+        g.Split(target, perturb, &h, MakeRandn(randn));
         if (!history.is_none()) for (int x : h) history.attr("append")(x);
+        return h;
       }, py::arg("target_components"), py::arg("perturb_factor"), py::arg("history") = py::none(), py::arg("randn") = py::none())
+      .def("gaussian_selection_1d", [](DiagGmm& g, Arr<float> x, int num_gselect) {
+        std::vector<int32_t> out;
+        const float f = g.GaussianSelection(x.data(), (size_t)x.size(), num_gselect, &out);
+        return py::make_tuple(f, out);
+      }, py::arg("data"), py::arg("num_gselect"))
+      .def("gaussian_selection_2d", [](DiagGmm& g, Arr<float> x, int num_gselect) {
+        if (x.ndim() != 2) throw Error("data must be a 2-D float matrix");
+        std::vector<std::vector<int32_t>> out;
+        const float f = g.GaussianSelectionMatrix(x.data(), (size_t)x.shape(0), (size_t)x.shape(1), num_gselect, &out);
+        return py::make_tuple(f, out);
+      }, py::arg("data"), py::arg("num_gselect"))
+      .def("gaussian_selection_preselect", [](DiagGmm& g, Arr<float> x, std::vector<int32_t> preselect, int num_gselect) {
+        std::vector<int32_t> out;
+        const float f = g.GaussianSelectionPreselect(x.data(), (size_t)x.size(), preselect, num_gselect, &out);
+        return py::make_tuple(f, out);
+      }, py::arg("data"), py::arg("preselect"), py::arg("num_gselect"))
       .def("merge", &DiagGmm::Merge, py::arg("target_components"))
       .def("perturb", [](DiagGmm& g, float pf, py::object randn) { g.Perturb(pf, MakeRandn(randn)); }, py::arg("perturb_factor"), py::arg("randn") = py::none())
       .def("generate", [](DiagGmm& g, py::object randn) { return Vec1(g.Generate(MakeRandn(randn))); }, py::arg("randn") = py::none())
