@@ -153,7 +153,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 1}, {0, 2}, {0, 1}, {0, 64}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 1}, {0, 64}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
@@ -176,7 +176,7 @@ static void ctx_defaults_from_env(khg_ctx* c) {
     {"KHG_K1_NF", KHG_OPT_K1_NF, ""}, {"KHG_K1P_TS", KHG_OPT_K1P_TS, ""}, {"KHG_K1_INTERLEAVE", KHG_OPT_K1_INTERLEAVE, ""},
     {"KHG_K1B_DBG", KHG_OPT_K1_DBG, ""}, {"KHG_K2_INORDER", KHG_OPT_K2_INORDER, ""}, {"KHG_K2_KS", KHG_OPT_K2_KS, ""},
     {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},
-    {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
+    {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1,count=2"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
     {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1"},
     {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}};
   c->opt[KHG_OPT_K1_INTERLEAVE] = -1;
@@ -515,6 +515,7 @@ struct khg_utts {
   // K3 scratch
   int32_t *pdf_count_d = nullptr, *pdf_cursor_d = nullptr, *frame_ids_d = nullptr;
   uint32_t *sort_keys_d = nullptr, *sort_keys_out_d = nullptr, *sort_vals_d = nullptr; void* sort_tmp_d = nullptr; size_t sort_tmp_bytes = 0;
+  int32_t* cs_hist_d = nullptr; size_t cs_hist_n = 0; int64_t* cs_tot_d = nullptr; size_t cs_tot_n = 0;   // counting-sort bucketing (k3_cs_*)
   double *k3_part_d = nullptr, *k3_llpart_d = nullptr; size_t k3_part_n = 0, k3_llpart_n = 0;   // wave-form K3: slice images / per-pdf log-likes
   int64_t* pdf_start_d = nullptr; unsigned long long* tid_count_d = nullptr;
   int32_t k3_P = 0, k3_tids = 0;
@@ -714,7 +715,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d); DEVFREE(u->k2_order_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
-  DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d);
+  DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d); DEVFREE(u->cs_hist_d); DEVFREE(u->cs_tot_d);
   DEVFREE(u->k3_part_d); DEVFREE(u->k3_llpart_d);
   if (u->ev_dp) (void)hipEventDestroy(u->ev_dp);
   if (u->ev_ali) (void)hipEventDestroy(u->ev_ali);
@@ -1775,6 +1776,30 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+      } else if (ctx->opt[KHG_OPT_K3_BUCKET] == 2 && m->P <= K3_CS_MAXP) {
+        // the library's own stable counting sort (khg_k3_accstats.hip.inc: k3_cs_*; opt-in: 1.27 ms against the radix sort's 0.80 at the
+        // bench size): blocks of CB consecutive frames
+        const int nw = m->P + 1 <= 7168 ? 4 : 2;                      // waves of a placing block: nw x (P + 1 + 1024) counters of LDS
+        int64_t CB = 32768;
+        while (CB > 64 * nw * 4 && (u->N + CB - 1) / CB < 1024) CB /= 2;   // enough blocks to fill the chip on small sets
+        const int nblk = (int)((u->N + CB - 1) / CB);
+        const size_t hist_n = (size_t)nblk * ((size_t)m->P + 1);
+        if (u->cs_hist_n < hist_n) { DEVFREE(u->cs_hist_d); rc = dev_alloc(&u->cs_hist_d, hist_n); if (rc) return rc; u->cs_hist_n = hist_n; }
+        if (u->cs_tot_n < (size_t)m->P + 1) { DEVFREE(u->cs_tot_d); rc = dev_alloc(&u->cs_tot_d, (size_t)m->P + 1); if (rc) return rc; u->cs_tot_n = (size_t)m->P + 1; }
+        K3CsArgs c{u->cs_hist_d, u->cs_tot_d, (int32_t)CB, nblk};
+        const bool ldst = tm->num_tids <= K3_LDS_TIDS;
+        const size_t lds_h = sizeof(unsigned int) * ((size_t)m->P + 1 + (ldst ? (size_t)tm->num_tids + 1 : 0));
+        const size_t lds_p = sizeof(unsigned int) * (size_t)nw * ((size_t)m->P + 1 + 1024);     // per-wave counters + the run-head hash tags
+        if (lds_h > 48 * 1024) {
+          HIPCHK(hipFuncSetAttribute((const void*)k3_cs_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+          HIPCHK(hipFuncSetAttribute((const void*)k3_cs_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+        }
+        if (lds_p > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k3_cs_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        if (ldst) hipLaunchKernelGGL(k3_cs_hist<true>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
+        else hipLaunchKernelGGL(k3_cs_hist<false>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
+        hipLaunchKernelGGL(k3_cs_scan, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, c);
+        hipLaunchKernelGGL(k3_cs_starts, dim3(1), dim3(1024), 0, ctx->stream, a, c);
+        hipLaunchKernelGGL(k3_cs_place, dim3(nblk), dim3(64 * nw), lds_p, ctx->stream, a, c);
       } else {
         // stable sort of (pdf, frame) pairs: frames of a pdf stay in frame order; the bucket boundaries are read
         // off the sorted keys

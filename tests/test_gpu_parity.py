@@ -490,6 +490,30 @@ def test_acc_stats_fp32_phase_b_option(ctx, opt):
         np.testing.assert_allclose(c["occ"], exact["occ"], rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("P,G,D,n_utt", [(12, 40, 23, 60), (300, 8, 13, 400), (3, 4, 40, 5)])
+def test_counting_sort_bucketing_equals_radix_sort_bit_for_bit(ctx, opt, P, G, D, n_utt):
+    """The library's own stable counting sort of the frames by pdf (k3_cs_hist / _scan / _starts / _place, k3_bucket = 2) puts
+    every frame where rocPRIM's stable radix sort of (pdf, frame) pairs does (the default): the statistics of the wave form,
+    which sums a pdf's frames in bucket order, are bit-identical; frames without a valid alignment (transition-id 0) stay out."""
+    from kaldi_hmm_gmm_amd import DeviceAccs
+
+    m, gc, om, ut, cost = build(P, G, D, n_utt=n_utt, seed=P + 1, ragged=True, max_phones=6)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    ali = ut.ref_ali.copy()
+    ali[::17] = 0                                   # unaligned frames scattered through the set
+    us.upload_ali(ali)
+    out = []
+    for mode in (0, 2, 0):
+        opt("k3_bucket", mode)
+        accs = DeviceAccs(ctx, dm, tm)
+        us.acc_stats(dm, tm, accs, weight=0.7)
+        st = accs.download()
+        out.append(np.concatenate([st["occ"], st["mean_acc"].ravel(), st["var_acc"].ravel(), st["trans_acc"],
+                                   [st["total_frames"], st["total_log_like"]]]))
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    assert out[0][-2] == pytest.approx(float(np.float32(0.7)) * (ali != 0).sum(), rel=1e-12)
+
+
 def test_acc_stats_reproducible_bit_for_bit(ctx, opt):
     """Wave-form K3 (the default for <= 64 Gaussians, D <= 40): stable bucket sort, per-pdf tile order, waves and pdf
     slices folded in a fixed order, one atomic per cell -- repeated passes give identical bits, with one block per pdf
