@@ -9,11 +9,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "_build", "cabi_client")
 
 
+HOST_BIN = os.path.join(ROOT, "tests", "_build", "host_client")
+
+
 def _build():
     import __graft_entry__ as g
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < os.path.getmtime(os.path.join(ROOT, "tests", "cabi_client.c")):
+    stale = lambda b, src: not os.path.exists(b) or os.path.getmtime(b) < os.path.getmtime(os.path.join(ROOT, "tests", src))      # noqa: E731
+    if stale(BIN, "cabi_client.c") or stale(HOST_BIN, "host_client.cpp"):
         g.build()
-    assert os.path.exists(BIN)
+    assert os.path.exists(BIN) and os.path.exists(HOST_BIN)
 
 
 def test_c_client_compiles_and_host_entry_points_run():
@@ -29,3 +33,19 @@ def test_c_client_em_pass_matches_oracle():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "CABI_CLIENT_OK" in r.stdout
+
+
+def test_cpp_host_classes_without_python():
+    """tests/host_client.cpp: HmmTopology, TransitionModel (+ MleUpdate), AmDiagGmm, AccumAmDiagGmm, MleAmDiagGmmUpdate,
+    MapAmDiagGmmUpdate, StdVectorFst, AddTransitionProbs, ModifyGraphForCarefulAlignment from a plain C++ program linked against
+    libkhg_hip.so -- the host classes carry no pybind11 / Python dependency."""
+    _build()
+    r = subprocess.run([HOST_BIN, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "HOST_CLIENT_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_classes_score_accumulate_and_align_on_the_gpu():
+    _build()
+    r = subprocess.run([HOST_BIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HOST_CLIENT_OK" in r.stdout, r.stdout + r.stderr
