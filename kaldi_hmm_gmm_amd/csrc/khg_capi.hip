@@ -1565,7 +1565,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const int KSsel = !fast ? 0 : ((ks_force == 2 || ks_force == 4) && !deg6 && S <= (size_t)1024 * ks_force ? ks_force : (S <= 1024 ? 1 : (S <= 2048 ? 2 : 4)));
   const size_t NSl = fast ? KSsel : 1;
   // trace-back block: fast = five groups of eight layers, one dword per lane and state slot; generic = 33 layers of bytes
-  const size_t tb_bytes = fast ? 5 * (size_t)nthr * NSl * 4 : (K2_FB + 1) * ((S + 15) & ~size_t(15));
+  // (fast: also the waves' strips of parked layer minima / counts, 2.5 KB each, in the same area during the forward pass)
+  const size_t tb_bytes = fast ? std::max<size_t>(5 * (size_t)nthr * NSl * 4, 2560 * nwave) : (K2_FB + 1) * ((S + 15) & ~size_t(15));
   // cur | nxt | reductions | arcs | in_off | wave minima/counts | flags | [align] | max(score block (generic), trace-back block)
   size_t lds_dp = 16 * S + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
                   std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), tb_bytes) + 64;
