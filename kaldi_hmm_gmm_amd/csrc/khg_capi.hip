@@ -1610,14 +1610,16 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   HIPCHK(hipStreamWaitEvent(side, u->ev_dp, 0));
   {
     KernelTimer kt(ctx, "k2_viterbi_faithful", side);
-    // wave-parallel form for the common training graphs (no epsilon-input arcs, <= 1000 states, out-degree <= 8);
-    // the one-lane form handles everything else
-    const int odeg = std::max(1, (int)u->max_outdeg);
-    const size_t lds_w = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 8 * (S + 1) + 5 * 4 * A + 8 * ((S * odeg + 63) / 64 + 2) + A + 64;
-    const bool wave_ok = !gmem && !u->has_eps && S <= 1000 && odeg <= 8 && lds_w <= 160 * 1024 && !ctx->opt[KHG_OPT_K2_SERIAL];
+    // wave-parallel form for graphs of <= 1000 states (any out-degree, epsilon-input arcs handled by a lane-0 worklist over
+    // the epsilon-capable tokens only); the one-lane form handles larger graphs and the HBM-scratch case
+    const int odeg_w = u->max_outdeg <= 8 ? std::max(1, (int)u->max_outdeg) : 0;     // 0: exact slot prefix sums
+    const size_t lds_w = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 8 * (S + 1) + 5 * 4 * A + 4 * max_npdf +
+                         (odeg_w ? 0 : 4 * A + 4 * S) + (u->has_eps ? 4 * S + 4 * (S + A + 1) + 4 * (S + 1) + 4 * A : 0) + 8 +
+                         8 * ((std::max(A, S * (size_t)odeg_w) + 63) / 64 + 1) + A + S + 64;
+    const bool wave_ok = !gmem && S <= 1000 && lds_w <= 160 * 1024 && !ctx->opt[KHG_OPT_K2_SERIAL];
     if (wave_ok) {
       if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
-      hipLaunchKernelGGL(k2_viterbi_faithful_wave, dim3(u->n_utt), dim3(64), lds_w, side, a, odeg);
+      hipLaunchKernelGGL(k2_viterbi_faithful_wave, dim3(u->n_utt), dim3(64), lds_w, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
     } else if (gmem) {
       hipLaunchKernelGGL(k2_viterbi_faithful<true>, dim3(u->n_utt), dim3(64), 0, side, a);
     } else {

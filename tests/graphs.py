@@ -54,3 +54,47 @@ def concat(gs):
     res["state_off"] = np.asarray(out["state_off"], np.int64)
     res["start"] = np.asarray(out["start"], np.int32)
     return res
+
+
+def hub_graph(rng, num_tids, fan=20, tail=6, eps_ties=True):
+    """A start state fanning out to `fan` branches (out-degree far above the arcs of a training graph), every branch a
+    short chain into a common tail; epsilon-input arcs in sequence and in parallel, some with EQUAL weights (which of two
+    equal-cost epsilon paths sets the back-pointer, and where a state first reached through an epsilon arc enters the
+    token list, depend on the reference's worklist order)."""
+    arcs = []
+    nxt = 1
+    join = 1 + 2 * fan                                    # first state of the common tail
+    for b in range(fan):
+        s1, s2 = nxt, nxt + 1
+        nxt += 2
+        arcs.append((0, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s1))
+        arcs.append((s1, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s1))
+        arcs.append((s1, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s2))
+        arcs.append((s2, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s2))
+        w = 0.25 if eps_ties else float(rng.random() * 0.3)
+        arcs.append((s2, 0, int(rng.integers(1, 50)), w, join))                      # eps:word into the tail (ties)
+        if b % 3 == 0:
+            arcs.append((s1, 0, 0, 0.125 if eps_ties else float(rng.random() * 0.3), s2))   # eps chain s1 -> s2 -> join
+        arcs.append((s2, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), join))
+    n = join + tail
+    for s in range(join, n):
+        arcs.append((s, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s + 1))
+        arcs.append((s, int(rng.integers(1, num_tids + 1)), 0, float(rng.random()), s))
+        if s + 2 <= n:
+            arcs.append((s, 0, int(rng.integers(1, 50)), 0.25 if eps_ties else float(rng.random() * 0.3), s + 2))
+            arcs.append((s, 0, 0, 0.125, s + 1))                                     # with s+1 -eps(0.125)-> s+2: equal-cost pair
+    arcs.append((n, int(rng.integers(1, num_tids + 1)), 0, 0.1, n))
+    S = n + 1
+    arcs.sort(key=lambda a: a[0])
+    arc_off = np.zeros(S + 1, np.int64)
+    for a in arcs:
+        arc_off[a[0] + 1] += 1
+    arc_off = np.cumsum(arc_off)
+    final = np.full(S, np.inf, np.float32)
+    final[n] = float(rng.random())
+    return {
+        "start": 0, "arc_off": arc_off,
+        "ilabel": np.array([a[1] for a in arcs], np.int32), "olabel": np.array([a[2] for a in arcs], np.int32),
+        "weight": np.array([a[3] for a in arcs], np.float32), "nextstate": np.array([a[4] for a in arcs], np.int32),
+        "final": final,
+    }

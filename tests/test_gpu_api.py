@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from graphs import concat, random_graph
+from graphs import concat, hub_graph, random_graph
 from helpers import build, oracle_graph, utt_feats
 from oracle import oracle as orc
 
@@ -404,6 +404,57 @@ def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, opt):
             if not (want["status"] & 1):
                 assert (a == want["ali"]).all(), (kw, u)
     assert seen > 20, "the fallback decoder was hardly exercised"
+
+
+def test_wave_faithful_decoder_epsilon_arcs_and_wide_fanout_equal_serial_and_oracle(ctx, opt):
+    """Graphs with epsilon-input arcs (chains, equal-cost parallel epsilon paths, word labels) and a start state of
+    out-degree 20: they have no beam certificate, so the order-faithful decoder IS their decoder.  The wave-parallel
+    form (exact slot prefix sums for any out-degree; ProcessNonemitting as a lane-0 worklist over the epsilon-capable
+    tokens, faster-decoder.cc:58-118) against the one-lane emulation and the oracle's FasterDecoder, token for token,
+    with beams that really prune and all GetCutoff branches."""
+    from kaldi_hmm_gmm_amd import synth
+
+    rng = np.random.default_rng(77)
+    m = synth.make_model(30, 2, 6, seed=9)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    graphs = [hub_graph(rng, m.num_tids, fan=int(rng.integers(9, 24)), tail=int(rng.integers(3, 9)), eps_ties=bool(i % 2)) for i in range(12)]
+    graphs += [random_graph(rng, m.num_tids, n_main=int(rng.integers(5, 60)), p_eps=float(rng.choice([0.3, 0.8])), p_branch=0.5, p_long=0.5)
+               for _ in range(28)]
+    T = [int(rng.integers(8, 60)) for g in graphs]
+    frame_off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+    feats = (rng.standard_normal((frame_off[-1], 6)) * 3).astype(np.float32)
+
+    class UT:
+        pass
+    ut = UT(); ut.frame_off = frame_off; ut.feats = feats; ut.graphs = concat(graphs)
+    cost = np.zeros(m.num_tids + 1, np.float32)
+    dm, tm, us = _dev(ctx, m, gc, ut, cost)
+    poff, pdfs = us.pdf_lists()
+    # scores on a coarse grid: exact cost ties between different paths really occur
+    mats = [(-0.25 * rng.integers(0, 24, size=(poff[u + 1] - poff[u], T[u]))).astype(np.float32) for u in range(us.n_utt)]
+    us.upload_loglikes(mats)
+    seen = 0
+    for kw in (dict(beam=200.0, retry_beam=0.0), dict(beam=1.5, retry_beam=6.0), dict(beam=3.0, retry_beam=0.0, max_active=12, min_active=3),
+               dict(beam=2.0, retry_beam=8.0, min_active=0), dict(beam=4.0, retry_beam=0.0, max_active=40, min_active=20, beam_delta=0.25)):
+        opt("k2_serial", 0)
+        rw = us.align(tm, acoustic_scale=1.0, **kw)
+        opt("k2_serial", 1)
+        rs = us.align(tm, acoustic_scale=1.0, **kw)
+        assert np.array_equal(rw["status"], rs["status"]), kw
+        assert np.array_equal(rw["ali"], rs["ali"]), kw
+        assert np.array_equal(rw["words"], rs["words"]) and np.array_equal(rw["words_off"], rs["words_off"]), kw
+        np.testing.assert_array_equal(rw["like"], rs["like"])
+        seen += int(((rw["status"] & 8) != 0).sum())
+        for u, g in enumerate(graphs):
+            og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+            want = orc.align_utterance_ll(og, m.id2pdf, T[u], pdfs[poff[u]: poff[u + 1]], mats[u], acoustic_scale=1.0, **kw)
+            assert (int(rw["status"][u]) & 3) == (want["status"] & 3), (kw, u)
+            a = rw["ali"][frame_off[u]: frame_off[u + 1]]
+            if not (want["status"] & 1):
+                assert (a == want["ali"]).all(), (kw, u)
+                w = rw["words"][rw["words_off"][u]: rw["words_off"][u + 1]]
+                assert (w == want["words"]).all(), (kw, u)
+    assert seen > 100, "the order-faithful decoder was hardly exercised"
 
 
 def test_accs_as_torch_aliases_the_device_block_and_all_reduces(ctx):

@@ -30,8 +30,50 @@ us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
 us.loglikes(dm, reachable_only=True); ctx.sync()
 for beam, retry in [(200, 0), (10, 40), (6, 40), (200, 0)]:
     res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1); ctx.sync()
+    ctx.set_timing(True)
     t0 = time.time()
     res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1); ctx.sync()
     dt = time.time() - t0
+    km = dict(ctx.timings()); ctx.set_timing(False)
     st = np.asarray(res["status"])
-    print(f"beam {beam}/{retry}: {dt*1e3:.1f} ms for {U} utts  exact_dp={(st & 4 > 0).sum()} fallback={(st & 8 > 0).sum()} retried={(st & 2 > 0).sum()} error={(st & 1).sum()}")
+    print(f"beam {beam}/{retry}: {dt*1e3:.1f} ms for {U} utts  exact_dp={(st & 4 > 0).sum()} fallback={(st & 8 > 0).sum()} retried={(st & 2 > 0).sum()} error={(st & 1).sum()}  kernels " +
+          ", ".join(f"{k} {v:.2f}" for k, v in km.items() if k.startswith("k2")))
+
+# --- the same set on graphs WITH epsilon-input arcs (no beam certificate: the order-faithful decoder is their decoder) ---
+# every phone-boundary state gets an epsilon arc that skips one HMM state at a price; the wave form (exact slot prefix sums,
+# lane-0 ProcessNonemitting over the epsilon-capable tokens) against the one-lane emulation and the epsilon-free numbers above
+def with_eps(g):
+    so, ao = g["state_off"], g["arc_off"]
+    NS = int(so[-1])
+    local = np.arange(NS) - np.repeat(so[:-1], np.diff(so))
+    last = np.repeat(np.diff(so) - 1, np.diff(so))
+    add = (local % 3 == 0) & (local + 1 <= last)
+    nar = np.diff(ao) + add
+    ao2 = np.concatenate([[0], np.cumsum(nar)]).astype(np.int64)
+    NA2 = int(ao2[-1])
+    out = {k: np.zeros(NA2, g[k].dtype) for k in ("ilabel", "olabel", "weight", "nextstate")}
+    # old arcs keep their order, the epsilon arc goes last in its state
+    old_pos = np.arange(int(ao[-1])) + np.repeat(ao2[:-1] - ao[:-1], np.diff(ao))
+    for k in out:
+        out[k][old_pos] = g[k]
+    ep = ao2[1:][add] - 1
+    out["ilabel"][ep] = 0; out["olabel"][ep] = 7; out["weight"][ep] = 2.0; out["nextstate"][ep] = local[add] + 1
+    return dict(g, arc_off=ao2, **out)
+
+use = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=with_eps(ut.graphs))
+use.loglikes(dm, reachable_only=True); ctx.sync()
+for serial in (0, 1):
+    ctx.set_option("k2_serial", serial)
+    for beam, retry in [(6, 40), (200, 0)]:
+        res = use.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1); ctx.sync()
+        ctx.set_timing(True)
+        t0 = time.time()
+        res = use.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1); ctx.sync()
+        dt = time.time() - t0
+        km = dict(ctx.timings()); ctx.set_timing(False)
+        st = np.asarray(res["status"])
+        print(f"eps graphs, {'one-lane' if serial else 'wave'} decoder, beam {beam}/{retry}: {dt*1e3:.1f} ms for {U} utts  fallback={(st & 8 > 0).sum()} retried={(st & 2 > 0).sum()} error={(st & 1).sum()}  kernels " +
+              ", ".join(f"{k} {v:.2f}" for k, v in km.items() if k.startswith("k2")))
+        if serial == 0: keep = res
+        else: print("   identical to the wave form:", bool(np.array_equal(keep["ali"], res["ali"]) and np.array_equal(keep["status"], res["status"])) if (beam, retry) == (200, 0) else "-")
+ctx.set_option("k2_serial", 0)
