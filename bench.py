@@ -320,17 +320,31 @@ def main():
 
     ar_events = []
 
+    dbg = os.environ.get("KHG_BENCH_HOSTDBG") == "1"
+    dbg_marks = []
+
     def step():
+        if dbg:
+            tt = [time.perf_counter()]
+            gm = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            gm[0].record(streams[0])
         accs.zero()                                   # on stream 0
+        if dbg: gm[1].record(streams[0])
         ev_a.record(streams[0])
         for st in streams[1:]:
             st.wait_event(ev_a)
-        for s_ in sets:                               # batches alternate between the two streams
-            s_.loglikes(dm, reachable_only=not args.full_loglikes)
-            s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=False)
         piped = dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1
+        for s_ in sets:                               # batches alternate between the two streams
+            if dbg: tt.append(time.perf_counter())
+            s_.loglikes(dm, reachable_only=not args.full_loglikes)
+            if dbg: tt.append(time.perf_counter()); gm[2].record(streams[0])
+            s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=False)
+            if dbg: tt.append(time.perf_counter()); gm[3].record(streams[0])
         for s_ in sets[:-1] if piped else sets:
             s_.acc_stats(dm, tm, accs)
+        if dbg:
+            tt.append(time.perf_counter()); gm[4].record(streams[0]); dbg_marks.append(gm)
+            print("step host ms:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in zip(tt[:-1], tt[1:])), file=sys.stderr)
         for st in streams[1:]:
             ev_b.record(st); streams[0].wait_event(ev_b)
         if dist_on:                                   # C1, on stream 0 right behind K3: no host synchronisation
@@ -371,14 +385,30 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    # as timeit does: no cyclic-GC pass inside the timed region (a full collection is several ms of host time; in the first
+    # step, when the GPU is idle, it delays the first launch directly -- later steps hide host time behind the running kernels)
+    import gc as pygc
+    pygc.collect(); pygc.disable()
     t0 = time.perf_counter()
+    if dbg:
+        marks = [torch.cuda.Event(enable_timing=True)]; marks[0].record(streams[0])
     for _ in range(args.steps):
         step()
+        if dbg:
+            print(f"issued at {(time.perf_counter() - t0) * 1e3:.2f} ms", file=sys.stderr)
+            marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record(streams[0])
     torch.cuda.synchronize()
+    if dbg:
+        print(f"drained at {(time.perf_counter() - t0) * 1e3:.2f} ms; stream-0 marks after each step (ms from the t0 mark): " +
+              " ".join(f"{marks[0].elapsed_time(m_):.2f}" for m_ in marks[1:]), file=sys.stderr)
+        for gm in dbg_marks[-args.steps:]:
+            print("  step on the GPU: from the t0 mark %.2f | zero %.2f  K1 %.2f  K2 %.2f  K3 %.2f" % (marks[0].elapsed_time(gm[0]), gm[0].elapsed_time(gm[1]),
+                  gm[1].elapsed_time(gm[2]), gm[2].elapsed_time(gm[3]), gm[3].elapsed_time(gm[4])), file=sys.stderr)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    pygc.enable()
     dt_local = dt
     for c in ctxs:
         for name, ms in c.timings():                  # HIP events on the launching stream

@@ -467,6 +467,7 @@ struct khg_utts {
   std::vector<int64_t> frame_off, state_off, pdf_off, ll_off, bp_off, path_off, words_off;
   std::vector<int32_t> pdfs;
   int32_t max_states = 0, max_inarcs = 0, max_indeg = 0, max_outdeg = 0;
+  int32_t pdfs_checked_P = -1;   // model size the pdf lists were last validated against
   bool has_eps = false;
   // device
   const float* feats_d = nullptr; bool own_feats = false;
@@ -1362,8 +1363,11 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
   if (u->pdf_first.size() != u->pdfs.size()) reachable_only = false;
   if (m->D != u->D) return khg_set_error(KHG_E_RUNTIME, "Dim mismatch: data dim = " + std::to_string(u->D) + " vs. model dim = " + std::to_string(m->D));
-  for (int32_t p : u->pdfs)
-    if (p < 0 || p >= m->P) return khg_set_error(KHG_E_RUNTIME, "Likely graph/model mismatch, e.g. using wrong HCLG.fst (pdf-id " + std::to_string(p) + ")");
+  if (u->pdfs_checked_P != m->P) {     // once per (set, model size): 7 M entries at the bench size, 1.5 ms of host time per call
+    for (int32_t p : u->pdfs)
+      if (p < 0 || p >= m->P) return khg_set_error(KHG_E_RUNTIME, "Likely graph/model mismatch, e.g. using wrong HCLG.fst (pdf-id " + std::to_string(p) + ")");
+    u->pdfs_checked_P = m->P;
+  }
   int rc = wait_ali(ctx, u);
   if (rc) return rc;
   if (!u->pdf_off_d) {
