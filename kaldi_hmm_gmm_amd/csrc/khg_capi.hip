@@ -1595,12 +1595,16 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     KernelTimer kt(ctx, "k2_viterbi_dp");
     hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false, true>), dim3(u->n_utt), dim3(nthr), 0, ctx->stream, a);
   } else {
-    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
+    // in-degree <= 2 (a linear transcript's chain of HMM states: self-loop + forward arc): the two-slot instantiation, a sixth fewer
+    // instructions per layer than the three-slot one (the layer loop is bound by VALU issue; every slot is evaluated, empty or not)
+    const bool deg2 = fast && !deg6 && KSsel == 1 && u->max_indeg <= 2 && ctx->opt[KHG_OPT_K2_KS] != 3;
+    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : deg2 ? (const void*)k2_viterbi_dp<1, 2, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
                      : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
     if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
     if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     KernelTimer kt(ctx, "k2_viterbi_dp");
     if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else if (deg2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 2) hipLaunchKernelGGL((k2_viterbi_dp<2, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 4) hipLaunchKernelGGL((k2_viterbi_dp<4, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
