@@ -467,6 +467,7 @@ struct khg_utts {
   std::vector<int64_t> frame_off, state_off, pdf_off, ll_off, bp_off, path_off, words_off;
   std::vector<int32_t> pdfs;
   int32_t max_states = 0, max_inarcs = 0, max_indeg = 0, max_outdeg = 0;
+  bool same_col = true;          // every state's in-arcs read one score row (reorder = true training graphs)
   int32_t pdfs_checked_P = -1;   // model size the pdf lists were last validated against
   bool has_eps = false;
   // device
@@ -656,6 +657,9 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
           out_inidx[a] = (int32_t)(pos - a0);
         }
       }
+      for (int64_t s = 0; s < S && u->same_col; ++s)
+        for (int64_t k = in_off[s0 + s] + 1; k < in_off[s0 + s + 1]; ++k)
+          if (in_col[k] != in_col[in_off[s0 + s]]) { u->same_col = false; break; }
       // generic path: one byte per (layer, state); fast path: one dword per (group of eight layers, lane), whole waves
       u->bp_off[i + 1] = u->bp_off[i] + std::max<int64_t>((T + 1) * std::max<int64_t>((S + 15) & ~int64_t(15), 512), ((T >> 3) + 1) * (S + 256) * 4);
       u->path_off[i + 1] = u->path_off[i] + T + S + 8;
@@ -1598,12 +1602,15 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     // in-degree <= 2 (a linear transcript's chain of HMM states: self-loop + forward arc): the two-slot instantiation, a sixth fewer
     // instructions per layer than the three-slot one (the layer loop is bound by VALU issue; every slot is evaluated, empty or not)
     const bool deg2 = fast && !deg6 && KSsel == 1 && u->max_indeg <= 2 && ctx->opt[KHG_OPT_K2_KS] != 3;
-    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : deg2 ? (const void*)k2_viterbi_dp<1, 2, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
+    // (KHG_K2_KS = 3: the general three-slot kernel, for the A/B)
+    const bool sc2 = deg2 && u->same_col;     // ... and one score row per state: one score block / cost conversion per state
+    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : sc2 ? (const void*)k2_viterbi_dp<1, 2, true, false, true> : deg2 ? (const void*)k2_viterbi_dp<1, 2, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
                      : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
     if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
     if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     KernelTimer kt(ctx, "k2_viterbi_dp");
     if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else if (sc2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true, false, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (deg2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 2) hipLaunchKernelGGL((k2_viterbi_dp<2, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
