@@ -93,7 +93,7 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_K1_INTERLEAVE 4  /* fp32 utterance-major K1: frame tiles dealt round-robin (-1 auto, 0, 1)        [KHG_K1_INTERLEAVE] */
 #define KHG_OPT_K1_DBG 5         /* experiment bit mask of the tile-major split forms (results may be WRONG)      [KHG_K1B_DBG] */
 #define KHG_OPT_K2_INORDER 6     /* 1: K2 workgroups in utterance order instead of longest first                  [KHG_K2_INORDER] */
-#define KHG_OPT_K2_KS 7          /* states per thread on K2's register-resident path: 0 auto, 2, 4                [KHG_K2_KS] */
+#define KHG_OPT_K2_KS 7          /* states per thread on K2's register-resident path: 0 auto, 2, 4; 3 = the general three-slot kernel also where the two-slot one applies [KHG_K2_KS] */
 #define KHG_OPT_K2_SERIAL 8      /* 1: the one-lane order-faithful decoder also where the wave form applies       [KHG_K2_SERIAL] */
 #define KHG_OPT_K2_PROF 9        /* 1: per-utterance cycle stamps of K2 to stderr                                 [KHG_K2_PROF] */
 #define KHG_OPT_K3_BUCKET 10     /* frames by pdf: 0 stable radix sort of (pdf, frame) pairs (rocPRIM; reproducible sums), 1 atomic cursor scatter, 2 the library's own stable counting sort (same order as 0, slower) [KHG_K3_BUCKET=sort|atomic|count] */
@@ -101,7 +101,8 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_K3_PHASE_B 12    /* gamma . x: 0 on the fp64 matrix pipe (exact products), 1 fp32 pipe, 256-frame fp32 partial sums [KHG_K3_PHASEB=f32] */
 #define KHG_OPT_K3_NY 13         /* workgroups per pdf in K3 (0 auto)                                             [KHG_K3_NY] */
 #define KHG_OPT_DEBUG 14         /* 1: planning statistics to stderr                                              [KHG_DEBUG] */
-#define KHG_OPT_COUNT 15
+#define KHG_OPT_K3_PHASE_A 15    /* per-Gaussian log-likelihoods of K3's wave form: 0 on the fp16 matrix cores in K1's f16x2s arithmetic where the model-derived scales hold, 1 the fp32 MFMA chain [KHG_K3_PHASEA=f32] */
+#define KHG_OPT_COUNT 16
 int khg_ctx_set_option(khg_ctx *ctx, int option, int value);
 int khg_ctx_get_option(const khg_ctx *ctx, int option, int *value);
 

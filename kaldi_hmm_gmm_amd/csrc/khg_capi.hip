@@ -153,7 +153,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 1}, {0, 64}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 1}, {0, 64}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
@@ -178,7 +178,7 @@ static void ctx_defaults_from_env(khg_ctx* c) {
     {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},
     {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1,count=2"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
     {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1"},
-    {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}};
+    {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}, {"KHG_K3_PHASEA", KHG_OPT_K3_PHASE_A, "auto=0,f16=0,f32=1"}};
   c->opt[KHG_OPT_K1_INTERLEAVE] = -1;
   c->opt[KHG_OPT_K1P_TS] = 1024;
   for (const auto& t : tab) {
@@ -317,6 +317,12 @@ struct khg_model {
   std::vector<int32_t> xs_ex_seen; // element-wise minimum of the feature exponents of the sets scored so far (f16x2s)
   ImgSync wimgs_sync;
   std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
+  // K3's fp16 phase A (k3_accumulate_wave<NB, true>): scale exponents derived from the model alone; cleared with wmax
+  std::vector<float> k3_xb;        // per dim: max over the Gaussians of |mean| + 8 sigma (empty: not computed)
+  std::vector<int32_t> k3_ex;      // [80] per k = 2 d + kind
+  int32_t k3_S = 0;
+  bool k3_f16_ok = false;          // the model side of the form's domain holds
+  int32_t* k3_ex_d = nullptr;
   float gcmax = 0.0f;              // max |gconst| over the finite ones (valid with wmax)
   int32_t* tile_pdf_d = nullptr;   // tile -> pdf map of the current layout
   K4Res* k4_res_d = nullptr;       // per-pdf results of the M-step in progress (khg_model_mle_update*)
@@ -343,7 +349,7 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     // any-dimension model (D > 80): no tile images; K3 still reads -0.5 * inv_vars
     m->KS = 0;
     m->wimgb_valid = false;
-    m->wimgh_ex.clear(); m->wimgs_key.clear(); m->wmax.clear();
+    m->wimgh_ex.clear(); m->wimgs_key.clear(); m->wmax.clear(); m->k3_xb.clear();
     const int64_t n = m->sumG * D;
     hipLaunchKernelGGL(k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
     hipError_t e = hipGetLastError();
@@ -365,7 +371,7 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
   DEVFREE(m->tile_pdf_d);
   m->wimgh_ex.clear();
   m->wimgs_key.clear();
-  m->wmax.clear();
+  m->wmax.clear(); m->k3_xb.clear();
   int rc = dev_upload(ctx, &m->tile_pdf_d, tile_pdf);
   int32_t* tile_pdf_d = m->tile_pdf_d;
   if (!rc) {
@@ -412,7 +418,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
@@ -1755,6 +1761,77 @@ static int accs_allreduce_pieces(khg_ctx* ctx, khg_accs* a, const khg_model* m, 
 static int ctx_comm_stream(khg_ctx* ctx);
 // K3, optionally with C1 pipelined behind it: the pdfs are cut into `nparts` ranges; the accumulate kernels of range i + 1 run on
 // the context's stream while the all-reduce of range i's accumulator rows runs on the context's communication stream.
+// K3's phase A on the fp16 matrix cores (khg_k3_accstats.hip.inc, k3_accumulate_wave<NB, true>): the scale exponents come from the
+// MODEL alone -- every rank of a sharded run derives the same ones, so the statistics do not depend on the sharding: per
+// dimension the features are expected inside xb = max_g (|mean| + 8 sigma); x' = x 2^ex peaks in [2^12, 2^13) there (fp16 overflows
+// at ~8 xb), fl(x^2)' in [2^9, 2^10) (same limit), and the largest weight column peaks in [2^14, 2^15) (S).  *use = false (the fp32
+// phase A runs) when the model side of the f16x2s domain fails (khg_k1_f16x2s.hip.inc: the absolute part of the error bound,
+// evaluated at xb, above 4e-6; |S| > 40; the log-sum-exp's 2^28 bound at 16 xb) or when a feature of THIS set overflows fp16.
+static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use) {
+  *use = false;
+  const int D = m->D, K = 80;
+  if (m->KQ != 10 || D > 40) return KHG_OK;
+  std::vector<float> xk;
+  int rc = k1_maxima(ctx, m, u, &xk);          // the set's column maxima (cached) and the model's (wmax, gcmax; cached per version)
+  if (rc) return rc;
+  if (m->k3_xb.empty()) {
+    uint32_t* b_d = nullptr;
+    rc = dev_alloc(&b_d, 64);
+    if (rc) return rc;
+    std::vector<uint32_t> hb(64, 0);
+    hipError_t e = hipMemsetAsync(b_d, 0, 64 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) {
+      const int64_t n = m->sumG;
+      hipLaunchKernelGGL(k3_model_xbound, dim3((int)std::min<int64_t>(2048, (n * D + 255) / 256)), dim3(256), 0, ctx->stream, m->miv_d, m->iv_d, n, D, b_d);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), b_d, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    DEVFREE(b_d);
+    if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    m->k3_xb.assign((size_t)D, 0.0f);
+    for (int d = 0; d < D; ++d) memcpy(&m->k3_xb[(size_t)d], &hb[(size_t)d], sizeof(float));
+    m->k3_ex.assign((size_t)K, 0);
+    bool ok = true;
+    for (int d = 0; d < D; ++d) {
+      const float xb = m->k3_xb[(size_t)d];
+      if (!(xb > 0.0f) || !(xb < 1.0e18f)) { ok = false; break; }
+      m->k3_ex[(size_t)2 * d] = 12 - std::ilogb(xb);               // xb 2^ex in [2^12, 2^13): fp16 overflows beyond 8 xb
+      m->k3_ex[(size_t)2 * d + 1] = 9 - std::ilogb(xb * xb);        // xb^2 2^ex in [2^9, 2^10): beyond 8 xb as well
+    }
+    int S = INT_MAX;
+    if (ok) {
+      for (int k = 0; k < 2 * D; ++k) if (m->wmax[(size_t)k] > 0.0f) S = std::min(S, 14 - std::ilogb(m->wmax[(size_t)k]) + m->k3_ex[(size_t)k]);
+      if (S == INT_MAX) S = 0;
+      if (S < -40 || S > 40) ok = false;
+    }
+    if (ok) {
+      double floor_sum = 0.0, bound = (double)m->gcmax;
+      for (int k = 0; k < 2 * D; ++k) {
+        const double xbk = (k & 1) ? (double)m->k3_xb[(size_t)(k >> 1)] * (double)m->k3_xb[(size_t)(k >> 1)] : (double)m->k3_xb[(size_t)(k >> 1)];
+        floor_sum += std::ldexp((double)m->wmax[(size_t)k], S - m->k3_ex[(size_t)k]) + std::ldexp(xbk, m->k3_ex[(size_t)k]);
+        bound += (double)m->wmax[(size_t)k] * xbk * ((k & 1) ? 128.0 : 16.0);
+      }
+      // (4e-6: the headroom for features outside the model's envelope costs two bits against K1s, whose planes peak at 2^14 by
+      //  construction; the fp32 chain this replaces carries ~7e-7 B, i.e. ~1e-4 at the same shapes)
+      if (!(std::ldexp(floor_sum, -25 - S) <= 4.0e-6) || !(bound <= 268435456.0)) ok = false;
+      if (ctx->opt[KHG_OPT_DEBUG]) fprintf(stderr, "[khg] K3 fp16 phase A: S %d, floor %.3g, bound %.3g -> %s\n", S, std::ldexp(floor_sum, -25 - S), bound, ok ? "on" : "off");
+    }
+    m->k3_S = ok ? S : 0;
+    m->k3_f16_ok = ok;
+    if (ok) {
+      if (!m->k3_ex_d) { rc = dev_alloc(&m->k3_ex_d, (size_t)K); if (rc) return rc; }
+      HIPCHK(hipMemcpyAsync(m->k3_ex_d, m->k3_ex.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  if (!m->k3_f16_ok) return KHG_OK;
+  for (int k = 0; k < 2 * D; ++k)
+    if (!(std::ldexp((double)xk[(size_t)k], m->k3_ex[(size_t)k]) < 65504.0)) return KHG_OK;     // a feature beyond 64 xb: fp32 phase A for this set
+  *use = true;
+  return KHG_OK;
+}
+
 static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
   if (!ctx || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
   if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
@@ -1783,6 +1860,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
   a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
   a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
   a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr; a.pdf0 = 0;
+  a.pa_ex = nullptr; a.pa_S = 0; a.pa_scale = 1.0f; a.pa_inv = 1.0f; a.pa_c1 = 1.44269504088896340736f;
   nparts = std::max(1, std::min(nparts, m->P));
   if (comm && nparts > 1) { rc = ctx_comm_stream(ctx); if (rc) return rc; }
   if (u->N > 0) {
@@ -1854,7 +1932,16 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     if (use_wave) {
       // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
       const int nb = (maxG + 15) / 16;
-      const size_t lds = std::max<size_t>(sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 4 * 16 * 20),
+      // phase A on the fp16 matrix cores where the model-derived scales hold (KHG_K3_PHASEA=f32 keeps the fp32 chain)
+      bool f16a = false;
+      if (ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] == 0) { rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &f16a); if (rc) return rc; }
+      if (f16a) {
+        a.pa_ex = m->k3_ex_d; a.pa_S = m->k3_S;
+        a.pa_scale = std::ldexp(1.0f, m->k3_S); a.pa_inv = std::ldexp(1.0f, -m->k3_S); a.pa_c1 = std::ldexp(1.44269504088896340736f, -m->k3_S);
+      }
+      // fp32 phase A: W + the waves' planes; fp16 phase A: the waves' planes + their split planes; then the fold image
+      const size_t lds = std::max<size_t>(f16a ? sizeof(float) * (4 * 4 * 16 * 20) + 2 * (size_t)(4 * 2 * 16 * K3_XH_ROW)
+                                               : sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 4 * 16 * 20),
                                           sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
       const int64_t avg_tiles = (u->N / std::max(1, m->P) + 15) / 16;
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, (avg_tiles + 15) / 16), (4096 + m->P - 1) / m->P));
@@ -1890,7 +1977,8 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
   do {                                                                                                                  \
     if (!exact_b && lds32 > 48 * 1024)                                                                                  \
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
-    if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(np, ny), dim3(256), lds, ctx->stream, a);            \
+    if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(np, ny), dim3(256), lds, ctx->stream, a);  \
+    else if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(np, ny), dim3(256), lds, ctx->stream, a);       \
     else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(np, ny), dim3(256), lds32, ctx->stream, a);                \
     if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a, ny);                 \
   } while (0)

@@ -367,14 +367,17 @@ def test_align_end_to_end(ctx):
         assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
 
 
-@pytest.mark.parametrize("k3_form", ["wave", "block", "valu"])
+@pytest.mark.parametrize("k3_form", ["wave", "wave_f32", "block", "valu"])
 @pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (30, 40, 13, True), (12, 128, 80, False)])
 def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
-    """All three K3 accumulate kernels: the wave-local MFMA form (default for <= 64 Gaussians, D <= 40), the
-    chunk-per-block MFMA form (option k3_form = 1; default for wider pdfs / features) and the VALU form
-    (k3_form = 2; default above 128 Gaussians)."""
+    """All three K3 accumulate kernels: the wave-local MFMA form (default for <= 64 Gaussians, D <= 40; its per-Gaussian
+    log-likelihoods on the fp16 matrix cores in K1's f16x2s arithmetic -- "wave" -- or as the fp32 MFMA chain -- "wave_f32",
+    option k3_phase_a = 1), the chunk-per-block MFMA form (option k3_form = 1; default for wider pdfs / features) and the
+    VALU form (k3_form = 2; default above 128 Gaussians)."""
     from kaldi_hmm_gmm_amd import DeviceAccs
 
+    if k3_form == "wave_f32":
+        opt("k3_phase_a", 1)
     if k3_form == "block":
         opt("k3_form", 1)
     elif k3_form == "valu":
@@ -400,7 +403,64 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
     np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
 
 
-@pytest.mark.parametrize("k3_form", ["wave", "block", "valu"])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_acc_stats_fp16_phase_a_against_fp64_posteriors_and_sharding(ctx, opt, overlap):
+    """K3's phase A on the fp16 matrix cores (f16x2s split, scale exponents from the model alone): its statistics lie as close to
+    an fp64 evaluation of the posteriors as the fp32 chain's do, and -- the exponents not depending on the utterances -- two
+    shards of a set add up to the statistics of the whole set to fp64 rounding."""
+    from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
+
+    m, gc, om, ut, cost = build(20, 64, 40, n_utt=24, seed=21, max_phones=6)
+    if overlap:                                   # posteriors spread over many components
+        means = (0.12 * m.means).astype(np.float32)
+        miv = (means * m.inv_vars).astype(np.float32)
+        gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, miv)
+    else:
+        miv = m.means_invvars
+    dm = DeviceModel(ctx, m.gauss_off, gc, miv, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+
+    def run(sel, phase_a):
+        opt("k3_phase_a", phase_a)
+        fo = np.concatenate([[0], np.cumsum(np.diff(ut.frame_off)[sel])]).astype(np.int64)
+        rows = np.concatenate([np.arange(ut.frame_off[u], ut.frame_off[u + 1]) for u in sel])
+        us = UtteranceSet(ctx, tm, fo, np.ascontiguousarray(ut.feats[rows]))
+        us.upload_ali(np.ascontiguousarray(ut.ref_ali[rows]))
+        accs = DeviceAccs(ctx, dm, tm)
+        us.acc_stats(dm, tm, accs, weight=1.0)
+        return accs.download()
+
+    every = np.arange(len(ut.frame_off) - 1)
+    f16 = run(every, 0)
+    f32 = run(every, 1)
+    # fp64 posteriors and sums on the host
+    X = ut.feats.astype(np.float64)
+    pdf = m.id2pdf[ut.ref_ali]
+    occ = np.zeros(int(m.gauss_off[-1])); macc = np.zeros((occ.size, 40)); tot = 0.0
+    for p in np.unique(pdf):
+        g0, g1 = int(m.gauss_off[p]), int(m.gauss_off[p + 1])
+        x = X[pdf == p]
+        ll = gc[g0:g1].astype(np.float64)[None, :] + x @ miv[g0:g1].astype(np.float64).T - 0.5 * (x * x) @ m.inv_vars[g0:g1].astype(np.float64).T
+        mx = ll.max(1, keepdims=True)
+        e = np.exp(ll - mx); z = e.sum(1, keepdims=True)
+        post = e / z
+        tot += float((np.log(z) + mx).sum())
+        occ[g0:g1] = post.sum(0); macc[g0:g1] = post.T @ x
+    big = occ > 1e-3
+    err16 = np.abs(f16["occ"] - occ)[big] / occ[big]
+    err32 = np.abs(f32["occ"] - occ)[big] / occ[big]
+    assert err16.max() <= max(2.0 * err32.max(), 2e-6), (err16.max(), err32.max())
+    assert f16["total_log_like"] == pytest.approx(tot, rel=2e-6)
+    e16 = np.abs(f16["mean_acc"] - macc).max(); e32 = np.abs(f32["mean_acc"] - macc).max()
+    assert e16 <= max(2.0 * e32, 2e-6 * np.abs(macc).max()), (e16, e32)
+    # sharding: halves of the set, fp16 phase A on both
+    a = run(every[::2], 0); b = run(every[1::2], 0)
+    for k in ("occ", "mean_acc", "var_acc"):
+        np.testing.assert_allclose(a[k] + b[k], f16[k], rtol=1e-11, atol=1e-11 * np.abs(f16[k]).max())
+    assert a["total_log_like"] + b["total_log_like"] == pytest.approx(f16["total_log_like"], rel=1e-12)
+
+
+@pytest.mark.parametrize("k3_form", ["wave", "wave_f32", "block", "valu"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (30, 24, 23), (12, 128, 80)])
 def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, opt):
     """The synthetic model's Gaussians are ~27 sigma apart (posteriors are one-hot, any softmax would do); here the
@@ -408,6 +468,8 @@ def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, opt):
     per-frame normalisation and the gamma-weighted sums are all exercised against the oracle."""
     from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet
 
+    if k3_form == "wave_f32":
+        opt("k3_phase_a", 1)
     if k3_form == "block":
         opt("k3_form", 1)
     elif k3_form == "valu":
@@ -464,6 +526,7 @@ def test_acc_stats_fp32_phase_b_option(ctx, opt):
     m, gc, om, ut, cost = build(20, 64, 40, n_utt=120, seed=33, max_phones=8)
     dm, tm, us = _device(ctx, m, gc, ut, cost)
     us.upload_ali(ut.ref_ali)
+    opt("k3_phase_a", 1)          # the fp32-pipe kernel keeps the fp32 phase A: compare it with the exact form on the same phase A
 
     def run():
         accs = DeviceAccs(ctx, dm, tm)
