@@ -1610,7 +1610,9 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     const bool deg2 = fast && !deg6 && KSsel == 1 && u->max_indeg <= 2 && ctx->opt[KHG_OPT_K2_KS] != 3;
     // (KHG_K2_KS = 3: the general three-slot kernel, for the A/B)
     const bool sc2 = deg2 && u->same_col;     // ... and one score row per state: one score block / cost conversion per state
-    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : sc2 ? (const void*)k2_viterbi_dp<1, 2, true, false, true> : deg2 ? (const void*)k2_viterbi_dp<1, 2, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
+    const bool sc3 = fast && !deg6 && !deg2 && KSsel == 1 && u->same_col && ctx->opt[KHG_OPT_K2_KS] != 3;   // three slots, one score row per state
+    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : sc2 ? (const void*)k2_viterbi_dp<1, 2, true, false, true> : deg2 ? (const void*)k2_viterbi_dp<1, 2, true> :
+                       sc3 ? (const void*)k2_viterbi_dp<1, 3, true, false, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
                      : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
     if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
     if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
@@ -1618,6 +1620,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (sc2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true, false, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (deg2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    else if (sc3) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true, false, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 2) hipLaunchKernelGGL((k2_viterbi_dp<2, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (KSsel == 4) hipLaunchKernelGGL((k2_viterbi_dp<4, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
@@ -1934,7 +1937,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       const int nb = (maxG + 15) / 16;
       // phase A on the fp16 matrix cores where the model-derived scales hold (KHG_K3_PHASEA=f32 keeps the fp32 chain)
       bool f16a = false;
-      if (ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] == 0) { rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &f16a); if (rc) return rc; }
+      // (pdfs of <= 32 Gaussians keep the fp32 chain: 40 MFMAs per tile are not worth the split, and the two-waves-per-SIMD
+      //  instantiations have no registers for the fp16 W pieces)
+      if (nb >= 3 && ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] == 0) { rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &f16a); if (rc) return rc; }
       if (f16a) {
         a.pa_ex = m->k3_ex_d; a.pa_S = m->k3_S;
         a.pa_scale = std::ldexp(1.0f, m->k3_S); a.pa_inv = std::ldexp(1.0f, -m->k3_S); a.pa_c1 = std::ldexp(1.44269504088896340736f, -m->k3_S);
