@@ -5,7 +5,7 @@ otherwise, and reproduces the status / retry / error semantics of AlignUtterance
 import numpy as np
 import pytest
 
-from graphs import random_graph
+from graphs import hub_graph, random_graph
 from oracle import oracle as orc
 
 
@@ -55,6 +55,31 @@ def test_faster_decoder_equals_exact_viterbi_when_beam_is_wide(seed):
     if (nb["status"] & 1) == 0:
         assert _path_cost(g, id2pdf, nb["ali"], ll, pdfs, 0.7) >= ex["cost"] - 1e-9
         assert len(nb["ali"]) == T
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_faster_decoder_on_hub_graphs_with_epsilon_ties(seed):
+    """The graphs of tests/test_gpu_api.py::test_wave_faithful_decoder_epsilon_arcs_and_wide_fanout_...: a start state fanning out
+    to 9-23 branches, epsilon chains and equal-cost epsilon pairs.  With a beam that cannot bite the oracle's FasterDecoder must
+    find the exact optimum of an independent Viterbi (tiny DP with an epsilon closure) -- ties may pick a different path, never a
+    different cost -- and with narrow beams never a better one."""
+    rng = np.random.default_rng(100 + seed)
+    num_tids = 20
+    id2pdf = np.concatenate([[0], rng.integers(0, 8, size=num_tids)]).astype(np.int32)
+    g = hub_graph(rng, num_tids, fan=int(rng.integers(9, 24)), tail=int(rng.integers(3, 9)), eps_ties=bool(seed % 2))
+    T = int(rng.integers(12, 40))
+    pdfs = np.arange(8, dtype=np.int32)
+    ll = (-0.25 * rng.integers(0, 24, size=(8, T))).astype(np.float32)      # coarse grid: exact cost ties between paths occur
+    og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+    ex = orc.exact_viterbi_ll(og, id2pdf, T, pdfs, ll, acoustic_scale=1.0)
+    fd = orc.align_utterance_ll(og, id2pdf, T, pdfs, ll, acoustic_scale=1.0, beam=1e4)
+    assert ex["status"] == 0 and fd["status"] == 0 and len(fd["ali"]) == T
+    assert _path_cost(g, id2pdf, fd["ali"], ll, pdfs, 1.0) == pytest.approx(ex["cost"], rel=1e-12)
+    for kw in (dict(beam=1.5, retry_beam=6.0), dict(beam=3.0, max_active=12, min_active=3), dict(beam=2.0, retry_beam=8.0, min_active=0)):
+        nb = orc.align_utterance_ll(og, id2pdf, T, pdfs, ll, acoustic_scale=1.0, **kw)
+        if (nb["status"] & 1) == 0:
+            assert len(nb["ali"]) == T
+            assert _path_cost(g, id2pdf, nb["ali"], ll, pdfs, 1.0) >= ex["cost"] - 1e-9
 
 
 def test_status_semantics():
