@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
     ap.add_argument("--k1", choices=["auto", "f16x2s", "f16x2", "bf16x3", "pdf", "utt"], default="auto",
-                    help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = f16x2 (fp16 matrix cores at fp32 accuracy, 3 partial "
+                    help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = f16x2s (fp16 matrix cores at fp32 accuracy, 3 partial "
                          "products); bf16x3 = bf16 matrix cores, 6 partial products; pdf / utt = the fp32-MFMA forms")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the two extra steps that time the fp32-MFMA K1 beside an f16x2 / bf16x3 run")
     ap.add_argument("--seed", type=int, default=20230418)

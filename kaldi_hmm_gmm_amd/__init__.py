@@ -1,5 +1,5 @@
 """kaldi_hmm_gmm_amd -- MI355X-native HMM-GMM EM hot path (K1 log-likes on the fp16 matrix cores at fp32 accuracy, K2 Viterbi
-forced alignment, K3 sufficient statistics on fp32 / fp64 MFMA, K4 device M-step, C1 RCCL sum) behind the names of the reference's
+forced alignment, K3 sufficient statistics (posteriors on fp16 / fp32 MFMA, sums on fp64 MFMA), K4 device M-step, C1 RCCL sum) behind the names of the reference's
 pybind11 module `kaldi_hmm_gmm` (python/kaldi_hmm_gmm/__init__.py) and of its scripts/*.py.
 
 Importing this package loads libkhg_hip.so; there is no CPU fallback."""
