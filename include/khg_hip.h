@@ -169,6 +169,10 @@ int khg_loglikes_download(khg_ctx *ctx, const khg_utts *u, float *ll_h);
 int khg_loglikes_upload(khg_ctx *ctx, khg_utts *u, const float *ll_h);
 /* features-only sets: give every utterance the same explicit pdf list */
 int khg_utts_set_pdf_list(khg_utts *u, int32_t n, const int32_t *pdfs_h);
+/* Borrowed device features (feats_d of khg_utts_create) are otherwise IMMUTABLE for the life of the handle: the default K1 keeps
+ * per-set data derived from them (column maxima, fp16 planes packed once).  A caller that rewrites them in place calls this
+ * before the next khg_loglikes; K3 and the fp32 K1 forms read feats_d live. */
+int khg_utts_features_changed(khg_utts *u);
 
 /* ---- K2: Viterbi forced alignment ------------------------------------------------------ */
 typedef struct {
@@ -181,6 +185,10 @@ typedef struct {
   int32_t min_active; /* 20 */
   float beam_delta;   /* 0.5 */
   float hash_ratio;   /* 2.0 */
+  /* divisor of `like` (decoder-wrappers.cc:95) when it differs from the scale the scores are multiplied by: the reference scales
+   * scores inside the decodable (its own `scale`) and divides `like` by AlignUtteranceWrapper's acoustic_scale argument.
+   * 0 = acoustic_scale (the scripts pass the same value for both). */
+  float like_scale;
 } khg_align_config;
 void khg_align_config_default(khg_align_config *c);
 

@@ -212,7 +212,30 @@ def get_stub_map(P: int, phone_sets: List[List[int]], phone2num_pdf_classes: Lis
     return SplitEventMap(P, first, map1, map2)
 
 
-class ContextDependency:
+class ContextDependencyInterface:
+    """csrc/context-dep.h (ContextDependencyInterface; python/csrc/context-dep.cc:17-53): what TransitionModel and the graph
+    compiler ask of a tree."""
+
+    @property
+    def context_width(self) -> int:
+        raise NotImplementedError
+
+    @property
+    def central_position(self) -> int:
+        raise NotImplementedError
+
+    @property
+    def num_pdfs(self) -> int:
+        raise NotImplementedError
+
+    def compute(self, phone_seq: List[int], pdf_class: int):
+        raise NotImplementedError
+
+    def get_pdf_info(self, phones: List[int], num_pdf_classes: List[int]) -> List[List[Tuple[int, int]]]:
+        raise NotImplementedError
+
+
+class ContextDependency(ContextDependencyInterface):
     """csrc/context-dep.h: (N, P, to_pdf)."""
 
     def __init__(self, N: int = 1, P: int = 0, to_pdf: Optional[EventMap] = None):
@@ -236,9 +259,9 @@ class ContextDependency:
     def to_pdf(self) -> EventMap:
         return self._to_pdf
 
-    def compute(self, phoneseq: List[int] = None, pdf_class: int = 0, phone_seq: List[int] = None):
-        """csrc/context-dep.cc:22-43 -> (ok, pdf_id)."""
-        seq = phone_seq if phoneseq is None else phoneseq
+    def compute(self, phone_seq: List[int], pdf_class: int):
+        """csrc/context-dep.cc:22-43 -> (ok, pdf_id)   (argument names of python/csrc/context-dep.cc:22-31)."""
+        seq = phone_seq
         if len(seq) != self._N:
             raise KhgError(f"ContextDependency::Compute: expected {self._N} phones, got {len(seq)}")
         event = {kPdfClass: int(pdf_class)}

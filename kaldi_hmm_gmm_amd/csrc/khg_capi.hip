@@ -708,6 +708,21 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear(); u->tiles_reach = -1;
   DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d); u->tiles2_pto.clear(); u->tiles2_reach = -1;
   DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d); u->p_reach = -1;
+  // the default K1's per-set unit table is indexed through pdf_off, and the id range check is cached per model size: both are stale now
+  DEVFREE(u->sunits_d); u->sunits_pto.clear(); u->sunits_reach = -1;
+  u->pdfs_checked_P = -1;
+  u->ll_valid = false;
+  return KHG_OK;
+}
+
+// Borrowed device features were rewritten in place: drop everything derived from them (column maxima, the fp16 / bf16 planes of the
+// split K1 forms); the next khg_loglikes re-packs.  K3 and the fp32 K1 forms read feats_d live.
+extern "C" int khg_utts_features_changed(khg_utts* u) {
+  if (!u) return khg_set_error(KHG_E_ARG, "khg_utts_features_changed: bad arguments");
+  u->xmax.clear();
+  u->xs_ks = 0; u->xs_ex.clear();
+  u->xh_ks = 0; u->xh_ex.clear();
+  u->xb3_ks = 0;
   u->ll_valid = false;
   return KHG_OK;
 }
@@ -1502,6 +1517,7 @@ extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
 extern "C" void khg_align_config_default(khg_align_config* c) {
   c->beam = 200.0f; c->retry_beam = 0.0f; c->careful = 0; c->acoustic_scale = 1.0f;
   c->max_active = INT32_MAX; c->min_active = 20; c->beam_delta = 0.5f; c->hash_ratio = 2.0f;
+  c->like_scale = 0.0f;
 }
 
 static int ensure_ali(khg_ctx* ctx, khg_utts* u) {
@@ -1562,6 +1578,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const bool k2prof = ctx->opt[KHG_OPT_K2_PROF] != 0;
   if (k2prof) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&a.prof), sizeof(long long) * 8 * (size_t)u->n_utt)); HIPCHK(hipMemset(a.prof, 0, sizeof(long long) * 8 * (size_t)u->n_utt)); }
   a.beam = cfg->beam; a.retry_beam = cfg->retry_beam; a.acoustic_scale = cfg->acoustic_scale;
+  a.like_scale = cfg->like_scale != 0.0f ? cfg->like_scale : cfg->acoustic_scale;
   a.beam_delta = cfg->beam_delta; a.hash_ratio = cfg->hash_ratio;
   a.max_active = cfg->max_active; a.min_active = cfg->min_active;
   a.max_states = u->max_states; a.max_inarcs = u->max_inarcs;
@@ -2041,11 +2058,19 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       a.pdf0 = 0;
     }
     HIPCHK(hipGetLastError());
+  } else if (comm && nparts > 1) {
+    // a rank without frames launches nothing but takes part in the same collectives, in the same order, as every other rank: the
+    // sequence is a function of (P, nparts) only
+    for (int part = 0; part < nparts; ++part) {
+      const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr);
+      if (rc) return rc;
+    }
   }
   if (comm) {
     // the rest of the block: all of it when nothing was pipelined, else the transition counts and the scalars; then the kernels'
     // stream waits for the communication stream
-    if (nparts > 1 && u->N > 0) rc = accs_allreduce_pieces(ctx, acc, m, -1, 0, comm, nullptr);
+    if (nparts > 1) rc = accs_allreduce_pieces(ctx, acc, m, -1, 0, comm, nullptr);
     else rc = khg_accs_allreduce(ctx, acc, comm);
     if (rc) return rc;
   }

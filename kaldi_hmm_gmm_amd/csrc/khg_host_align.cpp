@@ -46,7 +46,7 @@ std::string G(double x) { char b[64]; std::snprintf(b, sizeof(b), "%g", x); retu
 
 std::vector<AlignResult> AlignBatch(const AmDiagGmm& am, const TransitionModel& tm, const GraphsCsr& g, const std::vector<const float*>& feats,
                                     const std::vector<int64_t>& nframes, const AlignConfig& config, float acoustic_scale, const float* trans_cost,
-                                    const FasterDecoderOptions* dopts, bool return_scores) {
+                                    const FasterDecoderOptions* dopts, bool return_scores, float like_scale) {
   KHG_REQUIRE(!((config.retry_beam != 0 && config.retry_beam <= config.beam) || config.beam <= 0.0f),
               "Beams do not make sense: beam " + G(config.beam) + ", retry-beam " + G(config.retry_beam));   // csrc/decoder-wrappers.cc:29-33
   const int n_utt = (int)feats.size(), D = am.Dim();
@@ -71,6 +71,7 @@ std::vector<AlignResult> AlignBatch(const AmDiagGmm& am, const TransitionModel& 
   khg_align_config c;
   khg_align_config_default(&c);
   c.beam = config.beam; c.retry_beam = config.retry_beam; c.careful = config.careful ? 1 : 0; c.acoustic_scale = acoustic_scale;
+  c.like_scale = like_scale;
   if (dopts) { c.max_active = dopts->max_active; c.min_active = dopts->min_active; c.beam_delta = dopts->beam_delta; c.hash_ratio = dopts->hash_ratio; }
   const int64_t N = frame_off[(size_t)n_utt], wcap = N + 16 * (int64_t)n_utt + 1024;
   std::vector<int32_t> ali((size_t)std::max<int64_t>(N, 1)), words((size_t)wcap), status((size_t)n_utt);

@@ -46,6 +46,7 @@ class DecodableInterface {
 
 // csrc/decodable-am-diag-gmm.h:30-78: (frame, pdf-id + 1) -> log-likelihood.  Scores for every pdf are produced by one K1 launch
 // on first use and kept (the reference's one-frame cache).
+// NOTE (DecodableInterface above): LogLikelihood is declared const here; the reference's is non-const because of that cache.
 class DecodableAmDiagGmmUnmapped : public DecodableInterface {
  public:
   DecodableAmDiagGmmUnmapped(std::shared_ptr<AmDiagGmm> am, const float* feats, int64_t T, int D);
@@ -97,6 +98,8 @@ struct AlignResult {
 // only tells K2 the graphs were doubled (the caller applied ModifyGraphForCarefulAlignment / khg_careful_graph).
 std::vector<AlignResult> AlignBatch(const AmDiagGmm& am, const TransitionModel& tm, const GraphsCsr& graphs, const std::vector<const float*>& feats,
                                     const std::vector<int64_t>& nframes, const AlignConfig& config, float acoustic_scale, const float* trans_cost,
-                                    const FasterDecoderOptions* decoder_opts, bool return_scores);
+                                    const FasterDecoderOptions* decoder_opts, bool return_scores, float like_scale = 0.0f);
+// (like_scale: divisor of `like` when it is not the score scale -- a decodable whose own scale differs from the wrapper's
+// acoustic_scale argument, csrc/decoder-wrappers.cc:95; 0 = acoustic_scale)
 
 }  // namespace khg

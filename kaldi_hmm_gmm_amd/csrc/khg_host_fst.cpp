@@ -82,16 +82,114 @@ void FasterDecoder::InitDecoding() {
   has_res_ = false;
   nframes_ = 0;
 }
-void FasterDecoder::AdvanceDecoding(const std::shared_ptr<DecodableAmDiagGmmScaled>& dec, int max_num_frames) {
-  KHG_REQUIRE(dec != nullptr, "FasterDecoder: the HIP path needs a DecodableAmDiagGmmScaled");
+namespace {
+struct TmH { khg_tm* h = nullptr; ~TmH() { if (h) khg_tm_destroy(h); } };
+struct UttsH { khg_utts* h = nullptr; ~UttsH() { if (h) khg_utts_destroy(h); } };
+}  // namespace
+
+AlignResult AlignDecodable(const StdVectorFst& fst, const DecodableInterface& dec, const AlignConfig& config, float like_scale,
+                           const FasterDecoderOptions* dopts) {
+  KHG_REQUIRE(!((config.retry_beam != 0 && config.retry_beam <= config.beam) || config.beam <= 0.0f), "Beams do not make sense");
+  const int64_t T = dec.NumFramesReady();
+  AlignResult r;
+  r.num_frames = (int)T;
+  const GraphsCsr g = ConcatGraphs({&fst});
+  // the indices the decoder can ask for = the non-epsilon input labels of the graph; "pdf" j of the synthetic table is index j + 1
+  int max_index = 0;
+  for (int32_t l : g.ilabel) {
+    KHG_REQUIRE(l >= 0, "AlignDecodable: negative input label on the graph");
+    max_index = std::max(max_index, (int)l);
+  }
+  if (fst.Start() == kNoStateId || max_index == 0 || T <= 0) {       // nothing K2 could decode: same outcome as the GMM path
+    r.status = KHG_ALIGN_ERROR;
+    return r;
+  }
+  KHG_REQUIRE(max_index <= dec.NumIndices(), "AlignDecodable: the graph carries index " + std::to_string(max_index) + " but the decodable has " +
+                                                 std::to_string(dec.NumIndices()));
+  std::vector<int32_t> id2pdf((size_t)max_index + 1);
+  id2pdf[0] = -1;
+  for (int i = 1; i <= max_index; ++i) id2pdf[(size_t)i] = i - 1;
+  khg_ctx* ctx = DefaultCtx();
+  TmH dt; UttsH us;
+  CApi(khg_tm_create(ctx, max_index, id2pdf.data(), &dt.h));
+  const int64_t frame_off[2] = {0, T};
+  const std::vector<float> no_feats((size_t)T, 0.0f);                // K2 reads scores, never features
+  CApi(khg_utts_create(ctx, dt.h, 1, 1, frame_off, no_feats.data(), nullptr, g.state_off.data(), g.start.data(), g.arc_off.data(), g.ilabel.data(),
+                       g.olabel.data(), g.weight.data(), g.nextstate.data(), g.final_w.data(), &us.h));
+  int64_t pdf_off[2] = {0, 0}, ll_off[2] = {0, 0}, total = 0;
+  CApi(khg_utts_num_pdfs(us.h, pdf_off));
+  const int n = (int)pdf_off[1];
+  r.pdfs.resize((size_t)n);
+  CApi(khg_utts_pdfs(us.h, r.pdfs.data()));
+  CApi(khg_loglikes_layout(us.h, ll_off, &total));
+  const int64_t tpad = (T + 31) & ~int64_t(31);
+  KHG_REQUIRE(total >= (int64_t)n * tpad, "AlignDecodable: unexpected score layout");
+  std::vector<float> scores((size_t)total, 0.0f);
+  r.loglikes.resize((size_t)n * (size_t)T);
+  for (int j = 0; j < n; ++j)
+    for (int64_t t = 0; t < T; ++t) {
+      const float s = dec.LogLikelihood((int)t, r.pdfs[(size_t)j] + 1);
+      scores[(size_t)(ll_off[0] + (int64_t)j * tpad + t)] = s;
+      r.loglikes[(size_t)j * (size_t)T + (size_t)t] = s;
+    }
+  CApi(khg_loglikes_upload(ctx, us.h, scores.data()));
+  khg_align_config c;
+  khg_align_config_default(&c);
+  c.beam = config.beam; c.retry_beam = config.retry_beam; c.careful = config.careful ? 1 : 0;
+  c.acoustic_scale = 1.0f;                      // 1.0f * s == s: the decodable scaled its scores itself
+  c.like_scale = like_scale;
+  if (dopts) { c.max_active = dopts->max_active; c.min_active = dopts->min_active; c.beam_delta = dopts->beam_delta; c.hash_ratio = dopts->hash_ratio; }
+  const int64_t wcap = T + 1040;
+  std::vector<int32_t> ali((size_t)T), words((size_t)wcap);
+  int64_t woff[2] = {0, 0};
+  float like = 0.0f;
+  int32_t status = 0;
+  CApi(khg_align(ctx, dt.h, us.h, &c, ali.data(), words.data(), woff, wcap, &like, &status));
+  r.status = status;
+  r.ok = (status & KHG_ALIGN_ERROR) == 0;
+  r.retried = (status & KHG_ALIGN_RETRIED) != 0;
+  if (r.ok) {
+    r.alignment = std::move(ali);
+    r.words.assign(words.begin() + woff[0], words.begin() + woff[1]);
+    r.like = like;
+  }
+  return r;
+}
+
+void FasterDecoder::AdvanceDecoding(const std::shared_ptr<DecodableInterface>& dec, int max_num_frames) {
+  KHG_REQUIRE(dec != nullptr, "FasterDecoder: no decodable");
   KHG_REQUIRE(!(max_num_frames >= 0 && max_num_frames < dec->NumFramesReady()),
               "FasterDecoder.advanced_decoding: partial decoding (max_num_frames) is not supported on the HIP path");
   KHG_REQUIRE(nframes_ >= 0, "num_frames_decoded_ >= 0 assertion failed: call init_decoding() first");
   AlignConfig cfg;
   cfg.beam = cfg_.beam; cfg.retry_beam = 0.0f;
   dec_ = dec;
-  const GraphsCsr g = ConcatGraphs({fst_.get()});
-  res_ = AlignBatch(*dec->am(), *dec->tm(), g, {dec->feats().data()}, {(int64_t)dec->NumFramesReady()}, cfg, dec->scale(), nullptr, &cfg_, true)[0];
+  ac_.clear();
+  if (auto gmm = std::dynamic_pointer_cast<DecodableAmDiagGmmScaled>(dec)) {       // K1 + K2
+    const GraphsCsr g = ConcatGraphs({fst_.get()});
+    res_ = AlignBatch(*gmm->am(), *gmm->tm(), g, {gmm->feats().data()}, {(int64_t)gmm->NumFramesReady()}, cfg, gmm->scale(), nullptr, &cfg_, true)[0];
+    if (res_.ok) {
+      const TransitionModel& tm = *gmm->tm();
+      const size_t T = res_.alignment.size();
+      std::vector<int> col((size_t)tm.NumPdfs(), -1);
+      for (size_t i = 0; i < res_.pdfs.size(); ++i) col[(size_t)res_.pdfs[i]] = (int)i;
+      for (size_t i = 0; i < T; ++i) {
+        const int c = col[(size_t)tm.TransitionIdToPdf(res_.alignment[i])];
+        KHG_REQUIRE(c >= 0, "FasterDecoder: alignment uses a pdf outside the utterance's list");
+        ac_.push_back((double)(-(gmm->scale() * res_.loglikes[(size_t)c * T + i])));
+      }
+    }
+  } else {                                                                          // sampled scores + K2
+    res_ = AlignDecodable(*fst_, *dec, cfg, 0.0f, &cfg_);
+    if (res_.ok) {
+      const size_t T = res_.alignment.size();
+      for (size_t i = 0; i < T; ++i) {
+        const auto it = std::lower_bound(res_.pdfs.begin(), res_.pdfs.end(), res_.alignment[i] - 1);
+        KHG_REQUIRE(it != res_.pdfs.end() && *it == res_.alignment[i] - 1, "FasterDecoder: alignment uses an index outside the graph's");
+        ac_.push_back((double)(-res_.loglikes[(size_t)(it - res_.pdfs.begin()) * T + i]));
+      }
+    }
+  }
   has_res_ = true;
   nframes_ = dec->NumFramesReady();
 }
@@ -100,17 +198,9 @@ bool FasterDecoder::GetBestPath(LinearLattice* lat, bool use_final_probs) const 
   *lat = LinearLattice();
   if (!ReachedFinal()) return false;     // the reference would fall back to the best non-final token; the HIP kernels keep no such token
   const std::vector<int32_t>& ali = res_.alignment;
-  const TransitionModel& tm = *dec_->tm();
   const int T = (int)ali.size(), S = fst_->NumStates();
   const double INF = std::numeric_limits<double>::infinity();
-  std::vector<int> col((size_t)tm.NumPdfs(), -1);
-  for (size_t i = 0; i < res_.pdfs.size(); ++i) col[(size_t)res_.pdfs[i]] = (int)i;
-  std::vector<double> ac((size_t)T);
-  for (int i = 0; i < T; ++i) {
-    const int c = col[(size_t)tm.TransitionIdToPdf(ali[(size_t)i])];
-    KHG_REQUIRE(c >= 0, "FasterDecoder: alignment uses a pdf outside the utterance's list");
-    ac[(size_t)i] = (double)(-(dec_->scale() * res_.loglikes[(size_t)c * T + i]));
-  }
+  const std::vector<double>& ac = ac_;
   // cheapest path through the graph with exactly this input-label sequence (= the decoder's best path); layers keep their states
   // in insertion order, a later candidate replaces an earlier one only when strictly cheaper
   struct Back { int prev = -1, arc = -1; };       // arc = index into Arcs(prev)

@@ -50,6 +50,14 @@ void ModifyGraphForCarefulAlignment(StdVectorFst* fst);
 // csrc/hmm-utils.cc:465-493: arc.weight (x)= -scaled transition log-prob, in place
 void AddTransitionProbs(const TransitionModel& tm, const std::vector<int>& disambig_syms, float transition_scale, float self_loop_scale, StdVectorFst* fst);
 
+// AlignUtteranceWrapper / FasterDecoder::Decode for ANY DecodableInterface (csrc/decoder-wrappers.cc:16-108 takes a
+// DecodableInterface*, python/csrc/decodable-itf.cc:16-53 lets Python subclass it): the scores of every (frame, transition-id on
+// the graph) are sampled through the interface into K2's score matrix (khg_loglikes_upload) and K2 decodes them unscaled -- the
+// decodable already applied its own scale; `like` is divided by like_scale.  r.pdfs lists index - 1 for the sampled indices,
+// r.loglikes their [n][T] scores.
+AlignResult AlignDecodable(const StdVectorFst& fst, const DecodableInterface& decodable, const AlignConfig& config, float like_scale,
+                           const FasterDecoderOptions* decoder_opts);
+
 struct LatticeWeight {        // kaldifst LatticeWeight (graph cost, acoustic cost); Times adds component-wise
   double value1 = 0.0, value2 = 0.0;
 };
@@ -69,8 +77,9 @@ struct LinearLattice {
   bool GetLinearSymbolSequence(std::vector<int>* ilabels, std::vector<int>* olabels, LatticeWeight* total) const;
 };
 
-// python/csrc/faster-decoder.cc:33-53 on the GPU path: Decode runs K1 + K2 for the utterance of a DecodableAmDiagGmmScaled with the
-// options' beam / max_active / min_active / beam_delta / hash_ratio (no retry); GetBestPath rebuilds the linear lattice of
+// python/csrc/faster-decoder.cc:33-53 on the GPU path: Decode runs K1 + K2 for the utterance of a DecodableAmDiagGmmScaled (any other
+// DecodableInterface: its sampled scores + K2, AlignDecodable above) with the options' beam / max_active / min_active / beam_delta /
+// hash_ratio (no retry); GetBestPath rebuilds the linear lattice of
 // csrc/faster-decoder.cc:355-423 from the alignment: arc weights (graph cost, acoustic cost) per token, final weight, true epsilons
 // removed.  Whole utterances only: AdvanceDecoding with a frame limit is not supported.
 class FasterDecoder {
@@ -78,8 +87,8 @@ class FasterDecoder {
   FasterDecoder(std::shared_ptr<StdVectorFst> fst, const FasterDecoderOptions& config) : fst_(std::move(fst)) { SetOptions(config); }
   void SetOptions(const FasterDecoderOptions& config);
   void InitDecoding();
-  void Decode(const std::shared_ptr<DecodableAmDiagGmmScaled>& decodable) { InitDecoding(); AdvanceDecoding(decodable, -1); }
-  void AdvanceDecoding(const std::shared_ptr<DecodableAmDiagGmmScaled>& decodable, int max_num_frames);
+  void Decode(const std::shared_ptr<DecodableInterface>& decodable) { InitDecoding(); AdvanceDecoding(decodable, -1); }
+  void AdvanceDecoding(const std::shared_ptr<DecodableInterface>& decodable, int max_num_frames);
   int NumFramesDecoded() const { return nframes_; }
   bool ReachedFinal() const { return has_res_ && res_.ok; }
   bool GetBestPath(LinearLattice* lat, bool use_final_probs) const;
@@ -87,8 +96,9 @@ class FasterDecoder {
  private:
   std::shared_ptr<StdVectorFst> fst_;
   FasterDecoderOptions cfg_;
-  std::shared_ptr<DecodableAmDiagGmmScaled> dec_;
+  std::shared_ptr<DecodableInterface> dec_;
   AlignResult res_;
+  std::vector<double> ac_;           // acoustic cost of each aligned frame: -(score the decoder read for (frame, alignment[frame]))
   bool has_res_ = false;
   int nframes_ = -1;
 };

@@ -161,6 +161,25 @@ void DiagGmm::Resize(int nmix, int dim) {
   means_invvars_.assign((size_t)nmix * dim, 0.0f);
   valid_gconsts_ = false;
 }
+DiagGmm::DiagGmm(const std::vector<std::pair<float, const DiagGmm*>>& gmms) {
+  if (gmms.empty()) return;                    // an empty mixture
+  int num_gauss = 0;
+  const int dim = gmms[0].second->Dim();
+  for (auto& p : gmms) num_gauss += p.second->NumGauss();
+  Resize(num_gauss, dim);
+  size_t cur = 0;
+  for (auto& p : gmms) {
+    KHG_REQUIRE(p.first > 0.0f, "weight > 0.0 assertion failed");
+    const DiagGmm& g = *p.second;
+    KHG_REQUIRE(g.Dim() == dim || g.NumGauss() == 0, "DiagGmm(gmms): the mixtures differ in dimension");
+    const size_t n = (size_t)g.NumGauss();
+    std::copy(g.means_invvars_.begin(), g.means_invvars_.end(), means_invvars_.begin() + cur * dim);
+    std::copy(g.inv_vars_.begin(), g.inv_vars_.end(), inv_vars_.begin() + cur * dim);
+    for (size_t i = 0; i < n; ++i) weights_[cur + i] = p.first * g.weights_[i];
+    cur += n;
+  }
+  ComputeGconsts();
+}
 void DiagGmm::SetRaw(int G, int D, const float* w, const float* iv, const float* miv, const float* gc) {
   G_ = G; D_ = D;
   weights_.assign(w, w + G);

@@ -84,6 +84,8 @@ class DiagGmm {
  public:
   DiagGmm() = default;
   DiagGmm(int nmix, int dim) { Resize(nmix, dim); }
+  // the weighted concatenation of several mixtures, gconsts computed (csrc/diag-gmm.cc:68-101)
+  explicit DiagGmm(const std::vector<std::pair<float, const DiagGmm*>>& gmms);
   void Resize(int nmix, int dim);                              // csrc/diag-gmm.cc:30-47 (vars = 1)
   void CopyFromDiagGmm(const DiagGmm& o) { *this = o; }
   int NumGauss() const { return G_; }

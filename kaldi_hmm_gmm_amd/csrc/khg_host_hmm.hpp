@@ -82,6 +82,7 @@ class TransitionInformation {      // csrc/transition-information.h:26-77
   virtual bool IsSelfLoop(int trans_id) const = 0;
   virtual int TransitionIdToPdf(int trans_id) const = 0;
   virtual const std::vector<int>& TransitionIdToPdfArray() const = 0;
+  virtual int NumTransitionIds() const = 0;
   virtual int NumPdfs() const = 0;
 };
 
@@ -97,7 +98,7 @@ class TransitionModel : public TransitionInformation {
   void SetState(std::vector<TransitionModelTuple> tuples, std::shared_ptr<HmmTopology> topo, std::vector<int> state2id, std::vector<int> id2state,
                 std::vector<int> id2pdf, int num_pdfs, std::vector<float> log_probs, std::vector<float> nsl);
   void Check() const;
-  int NumTransitionIds() const { return (int)id2state_.size() - 1; }
+  int NumTransitionIds() const override { return (int)id2state_.size() - 1; }
   int NumTransitionStates() const { return (int)tuples_.size(); }
   int NumPdfs() const override { return num_pdfs_; }
   const std::vector<int>& TransitionIdToPdfArray() const override { return id2pdf_; }

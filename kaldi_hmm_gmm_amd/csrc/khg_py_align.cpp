@@ -182,30 +182,36 @@ void BindAlign(py::module_& m) {
 
   // python/csrc/decoder-wrappers.cc:25-47 -> (num_done, num_error, num_retried, tot_like, frame_count, alignment, words); the counters
   // are passed by value and returned incremented
-  m.def("align_utterance_wrapper", [](py::object config, const std::string&, float acoustic_scale, std::shared_ptr<StdVectorFst> fst, py::object decodable,
-                                      int num_done, int num_error, int num_retried, double tot_like, int64_t frame_count) {
-    if (!py::isinstance<DecodableAmDiagGmmScaled>(decodable)) throw Error("align_utterance_wrapper: the HIP path needs a DecodableAmDiagGmmScaled");
-    auto dec = decodable.cast<std::shared_ptr<DecodableAmDiagGmmScaled>>();
-    // the reference scales scores by the decodable's scale and `like` by acoustic_scale; the scripts pass the same value
-    if (dec->scale() != acoustic_scale) throw Error("align_utterance_wrapper: decodable scale and acoustic_scale must agree on this path");
+  // `decodable` is any DecodableInterface, as in the reference: a DecodableAmDiagGmmScaled runs K1 + K2 (scores scaled by the
+  // decodable's own scale, `like` divided by acoustic_scale, decoder-wrappers.cc:95); anything else -- the unmapped GMM decodable, a
+  // Python subclass of DecodableInterface -- has its scores sampled through log_likelihood(frame, index) and decoded by K2.
+  m.def("align_utterance_wrapper", [](py::object config, const std::string&, float acoustic_scale, std::shared_ptr<StdVectorFst> fst,
+                                      std::shared_ptr<DecodableInterface> decodable, int num_done, int num_error, int num_retried, double tot_like,
+                                      int64_t frame_count) {
+    if (!fst) throw Error("align_utterance_wrapper: fst is None");
+    if (!decodable) throw Error("align_utterance_wrapper: decodable is None");
     AlignConfig cfg = ConfigFrom(config);
     CheckBeams(cfg);
-    if (cfg.careful && fst->Start() != kNoStateId) {
+    if (fst->Start() == kNoStateId)                   // "Empty decoding graph" (decoder-wrappers.cc:35-41)
+      return py::tuple(py::make_tuple(num_done, num_error + 1, num_retried, tot_like, frame_count, py::list(), py::list()));
+    if (cfg.careful) {
       ModifyGraphForCarefulAlignment(fst.get());      // the reference mutates the caller's fst (decoder-wrappers.cc:43-45)
       cfg.careful = false;
     }
     AlignResult r;
-    {
+    if (auto dec = std::dynamic_pointer_cast<DecodableAmDiagGmmScaled>(decodable)) {
       py::gil_scoped_release nogil;
-      r = AlignBatch(*dec->am(), *dec->tm(), ConcatGraphs({fst.get()}), {dec->feats().data()}, {(int64_t)dec->NumFramesReady()}, cfg, acoustic_scale, nullptr,
-                     nullptr, false)[0];
+      r = AlignBatch(*dec->am(), *dec->tm(), ConcatGraphs({fst.get()}), {dec->feats().data()}, {(int64_t)dec->NumFramesReady()}, cfg, dec->scale(), nullptr,
+                     nullptr, false, acoustic_scale)[0];
+    } else {
+      r = AlignDecodable(*fst, *decodable, cfg, acoustic_scale, nullptr);       // GIL held: the scores may come from Python
     }
     if (r.retried) num_retried += 1;
     if (!r.ok) return py::tuple(py::make_tuple(num_done, num_error + 1, num_retried, tot_like, frame_count, py::list(), py::list()));
     return py::tuple(py::make_tuple(num_done + 1, num_error, num_retried, tot_like + (double)r.like, frame_count + (int64_t)r.num_frames, py::cast(r.alignment),
                                     py::cast(r.words)));
-  }, py::arg("config"), py::arg("utt"), py::arg("acoustic_scale"), py::arg("fst"), py::arg("decodable"), py::arg("num_done") = 0, py::arg("num_error") = 0,
-     py::arg("num_retried") = 0, py::arg("tot_like") = 0.0, py::arg("frame_count") = 0);
+  }, py::arg("config"), py::arg("utt"), py::arg("acoustic_scale"), py::arg("fst"), py::arg("decodable"), py::arg("num_done"), py::arg("num_error"),
+     py::arg("num_retried"), py::arg("tot_like"), py::arg("frame_count"));
 
   // ---- the graph container (kaldifst's method names) -----------------------------------------------------------------------------
   m.attr("kNoStateId") = kNoStateId;
@@ -261,11 +267,11 @@ void BindAlign(py::module_& m) {
   }, py::arg("fsts"));
   m.def("modify_graph_for_careful_alignment", [](StdVectorFst& f) { ModifyGraphForCarefulAlignment(&f); }, py::arg("fst"));
   // python/csrc/hmm-utils.cc:14-19: disambig_syms defaults to empty; the rest are required
-  m.def("add_transition_probs", [](const TransitionModel& tm, std::vector<int> disambig, py::object ts, py::object sl, py::object fst) {
-    if (ts.is_none() || sl.is_none() || fst.is_none()) throw py::type_error("add_transition_probs(): transition_scale, self_loop_scale and fst are required");
-    AddTransitionProbs(tm, disambig, ts.cast<float>(), sl.cast<float>(), fst.cast<std::shared_ptr<StdVectorFst>>().get());
-  }, py::arg("trans_model"), py::arg("disambig_syms") = std::vector<int>(), py::arg("transition_scale") = py::none(), py::arg("self_loop_scale") = py::none(),
-     py::arg("fst") = py::none());
+  // (pybind11 lets a defaulted argument precede required ones, as the reference's binding does)
+  m.def("add_transition_probs", [](const TransitionModel& tm, std::vector<int> disambig, float ts, float sl, std::shared_ptr<StdVectorFst> fst) {
+    if (!fst) throw Error("add_transition_probs: fst is None");
+    AddTransitionProbs(tm, disambig, ts, sl, fst.get());
+  }, py::arg("trans_model"), py::arg("disambig_syms") = std::vector<int>(), py::arg("transition_scale"), py::arg("self_loop_scale"), py::arg("fst"));
 
   py::class_<LatticeWeight>(m, "LatticeWeight")
       .def(py::init([](double a, double b) { return LatticeWeight{a, b}; }), py::arg("value1") = 0.0, py::arg("value2") = 0.0)
@@ -293,14 +299,9 @@ void BindAlign(py::module_& m) {
       .def(py::init<std::shared_ptr<StdVectorFst>, const FasterDecoderOptions&>(), py::arg("fst"), py::arg("config"))
       .def("set_options", &FasterDecoder::SetOptions, py::arg("config"))
       .def("init_decoding", &FasterDecoder::InitDecoding)
-      .def("decode", [](FasterDecoder& d, py::object dec) {
-        if (!py::isinstance<DecodableAmDiagGmmScaled>(dec)) throw Error("FasterDecoder: the HIP path needs a DecodableAmDiagGmmScaled");
-        d.Decode(dec.cast<std::shared_ptr<DecodableAmDiagGmmScaled>>());
-      }, py::arg("decodable"))
-      .def("advanced_decoding", [](FasterDecoder& d, py::object dec, int max_num_frames) {
-        if (!py::isinstance<DecodableAmDiagGmmScaled>(dec)) throw Error("FasterDecoder: the HIP path needs a DecodableAmDiagGmmScaled");
-        d.AdvanceDecoding(dec.cast<std::shared_ptr<DecodableAmDiagGmmScaled>>(), max_num_frames);
-      }, py::arg("decodable"), py::arg("max_num_frames") = -1)
+      .def("decode", [](FasterDecoder& d, std::shared_ptr<DecodableInterface> dec) { d.Decode(dec); }, py::arg("decodable"))
+      .def("advanced_decoding", [](FasterDecoder& d, std::shared_ptr<DecodableInterface> dec, int max_num_frames) { d.AdvanceDecoding(dec, max_num_frames); },
+           py::arg("decodable"), py::arg("max_num_frames") = -1)
       .def("num_frames_decoded", &FasterDecoder::NumFramesDecoded)
       .def("reached_final", &FasterDecoder::ReachedFinal)
       .def("get_best_path", [](FasterDecoder& d, bool use_final_probs) {

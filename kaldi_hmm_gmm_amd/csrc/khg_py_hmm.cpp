@@ -89,8 +89,9 @@ void BindHmm(py::module_& m) {
       .def_readwrite("share_for_pdfs", &MleTransitionUpdateConfig::share_for_pdfs);
 
   py::class_<TransitionModelTuple>(m, "TransitionModelTuple")
-      .def(py::init([](int ph, int hs, int fp, int sp) { return TransitionModelTuple{ph, hs, fp, sp}; }), py::arg("phone") = 0, py::arg("hmm_state") = 0,
-           py::arg("forward_pdf") = 0, py::arg("self_loop_pdf") = 0)
+      .def(py::init([]() { return TransitionModelTuple{0, 0, 0, 0}; }))
+      .def(py::init([](int ph, int hs, int fp, int sp) { return TransitionModelTuple{ph, hs, fp, sp}; }), py::arg("phone"), py::arg("hmm_state"),
+           py::arg("forward_pdf"), py::arg("self_loop_pdf"))
       .def_readwrite("phone", &TransitionModelTuple::phone)
       .def_readwrite("hmm_state", &TransitionModelTuple::hmm_state)
       .def_readwrite("forward_pdf", &TransitionModelTuple::forward_pdf)
@@ -110,10 +111,12 @@ void BindHmm(py::module_& m) {
       .def("is_self_loop", &TransitionInformation::IsSelfLoop, py::arg("trans_id"))
       .def("transition_id_to_pdf", &TransitionInformation::TransitionIdToPdf, py::arg("trans_id"))
       .def("transition_id_to_pdf_array", [](TransitionInformation& t) { return t.TransitionIdToPdfArray(); })
+      .def_property_readonly("num_transition_ids", &TransitionInformation::NumTransitionIds)
       .def_property_readonly("num_pdfs", &TransitionInformation::NumPdfs);
 
   py::class_<TransitionModel, TransitionInformation, std::shared_ptr<TransitionModel>>(m, "TransitionModel")
-      .def(py::init([](py::object ctx_dep, py::object hmm_topo) {
+      .def(py::init([]() { return std::make_shared<TransitionModel>(); }))
+      .def(py::init([](py::object ctx_dep, py::object hmm_topo) {       // (ctx_dep = None: an empty model over hmm_topo, what Read fills)
              if (ctx_dep.is_none()) {
                auto tm = std::make_shared<TransitionModel>();
                if (!hmm_topo.is_none())
@@ -129,7 +132,7 @@ void BindHmm(py::module_& m) {
              // ContextDependency::GetPdfInfo (csrc/context-dep.cc): pdf -> [(phone, pdf_class)]
              auto info = ctx_dep.attr("get_pdf_info")(phones, npc).cast<std::vector<std::vector<std::pair<int, int>>>>();
              return std::make_shared<TransitionModel>(info, topo);
-           }), py::arg("ctx_dep") = py::none(), py::arg("hmm_topo") = py::none())
+           }), py::arg("ctx_dep"), py::arg("hmm_topo"))
       .def("check", &TransitionModel::Check)
       .def_property_readonly("num_transition_ids", &TransitionModel::NumTransitionIds)
       .def_property_readonly("num_transition_states", &TransitionModel::NumTransitionStates)

@@ -42,6 +42,14 @@ py::array View2(std::vector<T>& v, size_t rows, size_t cols, py::handle owner) {
 }
 std::vector<float> FVec(const Arr<float>& a) { return std::vector<float>(a.data(), a.data() + a.size()); }
 
+// the calls below that reach the device (K1 / K3 / K4 through the C-ABI) run without the GIL: the argument arrays are owned by the
+// caller's frame for the duration of the call, and nothing inside touches a Python object
+template <class F>
+auto NoGil(F&& f) -> decltype(f()) {
+  py::gil_scoped_release release;
+  return f();
+}
+
 // the `randn` callables of the Python API: randn(d) -> d deviates, randn((rows, cols)) -> a matrix; None = numpy's global generator
 RandnFn MakeRandn(py::object randn) {
   return [randn](float* out, size_t rows, size_t cols) {
@@ -87,12 +95,20 @@ void BindGmm(py::module_& m) {
   }, py::arg("state_occs"), py::arg("target_components"), py::arg("power"), py::arg("min_count"));
 
   py::class_<DiagGmm, std::shared_ptr<DiagGmm>>(m, "DiagGmm")
-      .def(py::init([](int nmix, int dim, py::object gmm) {
-             if (!gmm.is_none()) return std::make_shared<DiagGmm>(*gmm.cast<std::shared_ptr<DiagGmm>>());
-             return std::make_shared<DiagGmm>(nmix, dim);
-           }), py::arg("nmix") = 0, py::arg("dim") = 0, py::arg("gmm") = py::none())
+      // the four constructors of python/csrc/diag-gmm.cc:18-22
+      .def(py::init([]() { return std::make_shared<DiagGmm>(); }))
+      .def(py::init([](const DiagGmm& gmm) { return std::make_shared<DiagGmm>(gmm); }), py::arg("gmm"))
+      .def(py::init([](int nmix, int dim) { return std::make_shared<DiagGmm>(nmix, dim); }), py::arg("nmix"), py::arg("dim"))
+      .def(py::init([](const std::vector<std::pair<float, std::shared_ptr<DiagGmm>>>& gmms) {
+             std::vector<std::pair<float, const DiagGmm*>> v;
+             for (auto& p : gmms) {
+               if (!p.second) throw Error("DiagGmm(gmms): a None entry");
+               v.emplace_back(p.first, p.second.get());
+             }
+             return std::make_shared<DiagGmm>(v);
+           }), py::arg("gmms"))
       .def("resize", &DiagGmm::Resize, py::arg("nmix"), py::arg("dim"))
-      .def("copy_from_diag_gmm", &DiagGmm::CopyFromDiagGmm)
+      .def("copy_from_diag_gmm", &DiagGmm::CopyFromDiagGmm, py::arg("diaggmm"))
       .def_property_readonly("num_gauss", &DiagGmm::NumGauss)
       .def_property_readonly("dim", &DiagGmm::Dim)
       .def_property_readonly("valid_gconsts", &DiagGmm::ValidGconsts)
@@ -116,24 +132,25 @@ void BindGmm(py::module_& m) {
                       g.mutable_means_invvars() = FVec(a);
                     })
       .def_property("_valid_gconsts", &DiagGmm::ValidGconsts, &DiagGmm::set_valid_gconsts)
-      .def("set_weights", [](DiagGmm& g, Arr<float> w) { g.SetWeights(w.data(), (size_t)w.size()); })
+      .def("set_weights", [](DiagGmm& g, Arr<float> w) { g.SetWeights(w.data(), (size_t)w.size()); }, py::arg("w"))
       .def("set_means", [](DiagGmm& g, Arr<float> a) {
         if (a.ndim() != 2) throw Error("SetMeans: shape mismatch");
         g.SetMeans(a.data(), (size_t)a.shape(0), (size_t)a.shape(1));
-      })
+      }, py::arg("m"))
       .def("set_invvars", [](DiagGmm& g, Arr<float> a) {
         if (a.ndim() != 2) throw Error("SetInvVars: shape mismatch");
         g.SetInvVars(a.data(), (size_t)a.shape(0), (size_t)a.shape(1));
-      })
+      }, py::arg("inv_vars"))
       .def("set_invvars_and_means", [](DiagGmm& g, Arr<float> v, Arr<float> mu) {
         if (v.ndim() != 2 || mu.ndim() != 2 || v.shape(0) != mu.shape(0) || v.shape(1) != mu.shape(1)) throw Error("SetInvVarsAndMeans: shape mismatch");
         g.SetInvVarsAndMeans(v.data(), mu.data(), (size_t)v.shape(0), (size_t)v.shape(1));
-      }, py::arg("invvars"), py::arg("means"))
+      }, py::arg("inv_vars"), py::arg("means"))
       .def("set_component_weight", &DiagGmm::SetComponentWeight, py::arg("gauss"), py::arg("weight"))
-      .def("set_component_mean", [](DiagGmm& g, int i, Arr<float> v) { g.SetComponentMean(i, v.data(), (size_t)v.size()); })
-      .def("set_component_inv_var", [](DiagGmm& g, int i, Arr<float> v) { g.SetComponentInvVar(i, v.data(), (size_t)v.size()); })
-      .def("get_component_mean", [](DiagGmm& g, int i) { return Vec1(g.GetComponentMean(i)); })
-      .def("get_component_variance", [](DiagGmm& g, int i) { return Vec1(g.GetComponentVariance(i)); })
+      .def("set_component_mean", [](DiagGmm& g, int i, Arr<float> v) { g.SetComponentMean(i, v.data(), (size_t)v.size()); }, py::arg("gauss"), py::arg("mean"))
+      .def("set_component_inv_var", [](DiagGmm& g, int i, Arr<float> v) { g.SetComponentInvVar(i, v.data(), (size_t)v.size()); }, py::arg("gauss"),
+           py::arg("inv_var"))
+      .def("get_component_mean", [](DiagGmm& g, int i) { return Vec1(g.GetComponentMean(i)); }, py::arg("gauss"))
+      .def("get_component_variance", [](DiagGmm& g, int i) { return Vec1(g.GetComponentVariance(i)); }, py::arg("gauss"))
       .def("remove_component", &DiagGmm::RemoveComponent, py::arg("gauss"), py::arg("renorm_weights"))
       .def("remove_components", &DiagGmm::RemoveComponents, py::arg("gauss"), py::arg("renorm_weights"))
       .def("compute_gconsts", &DiagGmm::ComputeGconsts)
@@ -145,14 +162,16 @@ void BindGmm(py::module_& m) {
         else go = {0, G};
         return py::make_tuple(Vec1(go), Vec1(g.gconsts()), Vec2(g.means_invvars(), G, g.Dim()), Vec2(g.inv_vars(), G, g.Dim()));
       })
-      .def("log_likelihood", [](DiagGmm& g, Arr<float> x) { return g.LogLikelihood(x.data(), (size_t)x.size()); })
-      .def("log_likelihoods", [](DiagGmm& g, Arr<float> x) { return Vec1(g.LogLikelihoods(x.data(), (size_t)x.size())); })
+      .def("log_likelihood", [](DiagGmm& g, Arr<float> x) { return NoGil([&] { return g.LogLikelihood(x.data(), (size_t)x.size()); }); }, py::arg("data"),
+           "Return the total loglikes in a float")
+      .def("log_likelihoods", [](DiagGmm& g, Arr<float> x) { return Vec1(NoGil([&] { return g.LogLikelihoods(x.data(), (size_t)x.size()); })); }, py::arg("data"),
+           "Return the loglike of each component in a 1-D tensor")
       .def("log_likelihoods_matrix", [](DiagGmm& g, Arr<float> x) {
         if (x.ndim() != 2 || x.shape(0) == 0) throw Error("data.rows() != 0 assertion failed");
-        return Vec2(g.LogLikelihoodsMatrix(x.data(), (size_t)x.shape(0), (size_t)x.shape(1)), (size_t)x.shape(0), (size_t)g.NumGauss());
-      })
+        return Vec2(NoGil([&] { return g.LogLikelihoodsMatrix(x.data(), (size_t)x.shape(0), (size_t)x.shape(1)); }), (size_t)x.shape(0), (size_t)g.NumGauss());
+      }, py::arg("data"), "data is a 2-D tensor of shape (N, dim); returns a 2-D tensor of shape (N, nmix) with the loglike of each component")
       .def("log_likelihoods_preselect", [](DiagGmm& g, Arr<float> x, std::vector<int64_t> idx) {
-        const std::vector<float> ll = g.LogLikelihoods(x.data(), (size_t)x.size());
+        const std::vector<float> ll = NoGil([&] { return g.LogLikelihoods(x.data(), (size_t)x.size()); });
         std::vector<float> out;
         for (int64_t i : idx) {
           if (i < 0) i += (int64_t)ll.size();
@@ -160,16 +179,16 @@ void BindGmm(py::module_& m) {
           out.push_back(ll[(size_t)i]);
         }
         return Vec1(out);
-      })
+      }, py::arg("data"), py::arg("indices"))
       .def("component_log_likelihood", [](DiagGmm& g, Arr<float> x, int comp) {
         if (comp < 0 || comp >= g.NumGauss()) throw Error("comp_id out of range");
-        return g.LogLikelihoods(x.data(), (size_t)x.size())[(size_t)comp];
-      })
+        return NoGil([&] { return g.LogLikelihoods(x.data(), (size_t)x.size()); })[(size_t)comp];
+      }, py::arg("data"), py::arg("comp_id"))
       .def("component_posteriors", [](DiagGmm& g, Arr<float> x) {
         std::vector<float> post;
-        const double ll = g.ComponentPosteriors(x.data(), (size_t)x.size(), &post);
+        const double ll = NoGil([&] { return g.ComponentPosteriors(x.data(), (size_t)x.size(), &post); });
         return py::make_tuple(ll, Vec1(post));
-      })
+      }, py::arg("data"))
       // -> the split history like python/csrc/diag-gmm.cc:69-77 (new component i + old count was split off component history[i]);
       // `history` (a list, extended too) and `randn` (the deviates, the reference draws them itself) are this package's additions
       .def("split", [](DiagGmm& g, int target, float perturb, py::object history, py::object randn) {
@@ -180,25 +199,25 @@ void BindGmm(py::module_& m) {
       }, py::arg("target_components"), py::arg("perturb_factor"), py::arg("history") = py::none(), py::arg("randn") = py::none())
       .def("gaussian_selection_1d", [](DiagGmm& g, Arr<float> x, int num_gselect) {
         std::vector<int32_t> out;
-        const float f = g.GaussianSelection(x.data(), (size_t)x.size(), num_gselect, &out);
+        const float f = NoGil([&] { return g.GaussianSelection(x.data(), (size_t)x.size(), num_gselect, &out); });
         return py::make_tuple(f, out);
       }, py::arg("data"), py::arg("num_gselect"))
       .def("gaussian_selection_2d", [](DiagGmm& g, Arr<float> x, int num_gselect) {
         if (x.ndim() != 2) throw Error("data must be a 2-D float matrix");
         std::vector<std::vector<int32_t>> out;
-        const float f = g.GaussianSelectionMatrix(x.data(), (size_t)x.shape(0), (size_t)x.shape(1), num_gselect, &out);
+        const float f = NoGil([&] { return g.GaussianSelectionMatrix(x.data(), (size_t)x.shape(0), (size_t)x.shape(1), num_gselect, &out); });
         return py::make_tuple(f, out);
       }, py::arg("data"), py::arg("num_gselect"))
       .def("gaussian_selection_preselect", [](DiagGmm& g, Arr<float> x, std::vector<int32_t> preselect, int num_gselect) {
         std::vector<int32_t> out;
-        const float f = g.GaussianSelectionPreselect(x.data(), (size_t)x.size(), preselect, num_gselect, &out);
+        const float f = NoGil([&] { return g.GaussianSelectionPreselect(x.data(), (size_t)x.size(), preselect, num_gselect, &out); });
         return py::make_tuple(f, out);
       }, py::arg("data"), py::arg("preselect"), py::arg("num_gselect"))
-      .def("merge", &DiagGmm::Merge, py::arg("target_components"))
+      .def("merge", &DiagGmm::Merge, py::arg("target_components"), py::call_guard<py::gil_scoped_release>())
       .def("perturb", [](DiagGmm& g, float pf, py::object randn) { g.Perturb(pf, MakeRandn(randn)); }, py::arg("perturb_factor"), py::arg("randn") = py::none())
       .def("generate", [](DiagGmm& g, py::object randn) { return Vec1(g.Generate(MakeRandn(randn))); }, py::arg("randn") = py::none())
       .def("interpolate", [](DiagGmm& g, float rho, const DiagGmm& src, int flags) { g.Interpolate(rho, src, flags); }, py::arg("rho"), py::arg("source"),
-           py::arg("flags") = 0x7)
+           py::arg("flags") = (int)kGmmAll)
       // pickle: (weights, inv_vars, means_invvars); gconsts are re-derived (python/csrc/diag-gmm.cc:157-167)
       .def(py::pickle(
           [](DiagGmm& g) { return py::make_tuple(Vec1(g.weights()), Vec2(g.inv_vars(), g.NumGauss(), g.Dim()), Vec2(g.means_invvars(), g.NumGauss(), g.Dim())); },
@@ -222,11 +241,11 @@ void BindGmm(py::module_& m) {
       .def("get_pdf", [](AmDiagGmm& a, int i) { return a.GetPdf(i); }, py::arg("pdf_index"))      // reference-returning, like the reference's binding
       .def_property("_pdfs", [](AmDiagGmm& a) { return a.pdfs(); }, [](AmDiagGmm& a, std::vector<std::shared_ptr<DiagGmm>> v) { a.pdfs() = std::move(v); })
       .def("compute_gconsts", &AmDiagGmm::ComputeGconsts)
-      .def("log_likelihood", [](AmDiagGmm& a, int i, Arr<float> x) { return a.GetPdf(i)->LogLikelihood(x.data(), (size_t)x.size()); }, py::arg("pdf_index"), py::arg("data"))
+      .def("log_likelihood", [](AmDiagGmm& a, int i, Arr<float> x) { return NoGil([&] { return a.GetPdf(i)->LogLikelihood(x.data(), (size_t)x.size()); }); }, py::arg("pdf_index"), py::arg("data"))
       .def("get_gaussian_mean", [](AmDiagGmm& a, int i, int g) { return Vec1(a.GetPdf(i)->GetComponentMean(g)); }, py::arg("pdf_index"), py::arg("gauss"))
       .def("get_gaussian_variance", [](AmDiagGmm& a, int i, int g) { return Vec1(a.GetPdf(i)->GetComponentVariance(g)); }, py::arg("pdf_index"), py::arg("gauss"))
       .def("set_gaussian_mean", [](AmDiagGmm& a, int i, int g, Arr<float> v) { a.GetPdf(i)->SetComponentMean(g, v.data(), (size_t)v.size()); },
-           py::arg("pdf_index"), py::arg("gauss_index"), py::arg("v"))
+           py::arg("pdf_index"), py::arg("gauss_index"), py::arg("in"))
       .def("split_pdf", [](AmDiagGmm& a, int i, int target, float pf) { a.GetPdf(i)->Split(target, pf, nullptr, MakeRandn(py::none())); },
            py::arg("pdf_idx"), py::arg("target_components"), py::arg("perturb_factor"))
       .def("split_by_count", [](AmDiagGmm& a, Arr<float> occs, int target, float pf, float power, double min_count, py::object randn) {
@@ -299,19 +318,16 @@ void BindGmm(py::module_& m) {
       .def("__str__", &MapDiagGmmOptions::ToString);
 
   py::class_<AccumDiagGmm, std::shared_ptr<AccumDiagGmm>>(m, "AccumDiagGmm")
-      .def(py::init([](py::object gmm, int flags) {
+      // python/csrc/mle-diag-gmm.cc:65-73: two constructors, resize(num_gauss, dim, flags); resize(gmm, flags) is this package's extra
+      .def(py::init([]() { return std::make_shared<AccumDiagGmm>(); }))
+      .def(py::init([](const DiagGmm& gmm, int flags) {
              auto a = std::make_shared<AccumDiagGmm>();
-             if (!gmm.is_none()) { auto g = gmm.cast<std::shared_ptr<DiagGmm>>(); a->Resize(g->NumGauss(), g->Dim(), flags); }
+             a->Resize(gmm.NumGauss(), gmm.Dim(), flags);
              return a;
-           }), py::arg("gmm") = py::none(), py::arg("flags") = 0)
-      .def("resize", [](AccumDiagGmm& a, py::object num_gauss, py::object dim, py::object flags) {
-        if (py::isinstance<DiagGmm>(num_gauss)) {          // resize(gmm, flags)
-          auto g = num_gauss.cast<std::shared_ptr<DiagGmm>>();
-          a.Resize(g->NumGauss(), g->Dim(), dim.cast<int>());
-        } else {
-          a.Resize(num_gauss.cast<int>(), dim.cast<int>(), flags.cast<int>());
-        }
-      }, py::arg("num_gauss"), py::arg("dim") = py::none(), py::arg("flags") = py::none())
+           }), py::arg("gmm"), py::arg("flags"))
+      .def("resize", [](AccumDiagGmm& a, int num_gauss, int dim, int flags) { a.Resize(num_gauss, dim, flags); }, py::arg("num_gauss"), py::arg("dim"),
+           py::arg("flags"))
+      .def("resize", [](AccumDiagGmm& a, const DiagGmm& gmm, int flags) { a.Resize(gmm.NumGauss(), gmm.Dim(), flags); }, py::arg("gmm"), py::arg("flags"))
       .def_property_readonly("num_gauss", &AccumDiagGmm::NumGauss)
       .def_property_readonly("dim", &AccumDiagGmm::Dim)
       .def_property_readonly("flags", &AccumDiagGmm::Flags)
@@ -340,7 +356,7 @@ void BindGmm(py::module_& m) {
       .def("accumulate_from_posteriors", [](AccumDiagGmm& a, Arr<float> x, Arr<float> post) {
         a.AccumulateFromPosteriors(x.data(), (size_t)x.size(), post.data(), (size_t)post.size());
       }, py::arg("data"), py::arg("gauss_posteriors"))
-      .def("accumulate_from_diag", [](AccumDiagGmm& a, const DiagGmm& g, Arr<float> x, float w) { return a.AccumulateFromDiag(g, x.data(), (size_t)x.size(), w); },
+      .def("accumulate_from_diag", [](AccumDiagGmm& a, const DiagGmm& g, Arr<float> x, float w) { return NoGil([&] { return a.AccumulateFromDiag(g, x.data(), (size_t)x.size(), w); }); },
            py::arg("gmm"), py::arg("data"), py::arg("weight"))
       .def("add_stats_for_component", [](AccumDiagGmm& a, int g, double occ, Arr<double> x, Arr<double> x2) {
         a.AddStatsForComponent(g, occ, x.data(), (size_t)x.size(), x2.data(), (size_t)x2.size());
@@ -348,10 +364,13 @@ void BindGmm(py::module_& m) {
       .def("add", &AccumDiagGmm::Add, py::arg("scale"), py::arg("acc"))
       .def("smooth_stats", &AccumDiagGmm::SmoothStats, py::arg("tau"))
       .def("smooth_with_accum", &AccumDiagGmm::SmoothWithAccum, py::arg("tau"), py::arg("src_acc"))
-      .def("smooth_with_model", &AccumDiagGmm::SmoothWithModel, py::arg("tau"), py::arg("gmm"))
+      .def("smooth_with_model", &AccumDiagGmm::SmoothWithModel, py::arg("tau"), py::arg("src_gmm"))
       .def("copy", [](AccumDiagGmm& a) { return std::make_shared<AccumDiagGmm>(a); });
 
-  m.def("mle_diag_gmm_update", [](py::object cfg, const AccumDiagGmm& acc, int flags, DiagGmm& gmm) { return UpdateTuple(MleDiagGmmUpdate(OptsFrom(cfg), acc, flags, &gmm)); },
+  m.def("mle_diag_gmm_update", [](py::object cfg, const AccumDiagGmm& acc, int flags, DiagGmm& gmm) {
+          const MleDiagGmmOptions o = OptsFrom(cfg);
+          return UpdateTuple(NoGil([&] { return MleDiagGmmUpdate(o, acc, flags, &gmm); }));
+        },
         py::arg("config"), py::arg("diag_gmm_acc"), py::arg("flags"), py::arg("gmm"));
   m.def("ml_objective", &MlObjective, py::arg("gmm"), py::arg("diaggmm_acc"));
   m.def("map_diag_gmm_update", [](const MapDiagGmmOptions& cfg, const AccumDiagGmm& acc, int flags, DiagGmm& gmm) { return MapDiagGmmUpdate(cfg, acc, flags, &gmm); },
@@ -377,11 +396,12 @@ void BindGmm(py::module_& m) {
 
   py::class_<AccumAmDiagGmm, std::shared_ptr<AccumAmDiagGmm>>(m, "AccumAmDiagGmm")
       .def(py::init<>())
-      .def("init", [](AccumAmDiagGmm& a, const AmDiagGmm& model, int dim_or_flags, py::object flags) {
-        if (flags.is_none()) { a.Init(model, -1, dim_or_flags); return; }
-        if (!(dim_or_flags > 0)) throw Error("dim > 0 assertion failed");
-        a.Init(model, dim_or_flags, flags.cast<int>());
-      }, py::arg("model"), py::arg("dim_or_flags"), py::arg("flags") = py::none())
+      // the two overloads of python/csrc/mle-am-diag-gmm.cc:18-23 (egs/yesno/train.py:111 calls init(model=, flags=))
+      .def("init", [](AccumAmDiagGmm& a, const AmDiagGmm& model, int flags) { a.Init(model, -1, flags); }, py::arg("model"), py::arg("flags"))
+      .def("init", [](AccumAmDiagGmm& a, const AmDiagGmm& model, int dim, int flags) {
+        if (!(dim > 0)) throw Error("dim > 0 assertion failed");
+        a.Init(model, dim, flags);
+      }, py::arg("model"), py::arg("dim"), py::arg("flags"))
       .def("set_zero", &AccumAmDiagGmm::SetZero, py::arg("flags"))
       .def_property_readonly("num_accs", &AccumAmDiagGmm::NumAccs)
       .def_property_readonly("dim", &AccumAmDiagGmm::Dim)
@@ -392,14 +412,16 @@ void BindGmm(py::module_& m) {
       .def_readwrite("_total_log_like", &AccumAmDiagGmm::total_log_like_)
       .def("get_acc", [](AccumAmDiagGmm& a, int i) { return std::make_shared<AccumDiagGmm>(*a.Acc(i)); }, py::arg("index"))   // the binding returns a COPY
       .def_property_readonly("_accs", [](AccumAmDiagGmm& a) { return a.accs(); })
-      .def("accumulate_for_gmm", [](AccumAmDiagGmm& a, const AmDiagGmm& model, Arr<float> x, int i, float w) { return a.AccumulateForGmm(model, x.data(), (size_t)x.size(), i, w); },
+      .def("accumulate_for_gmm", [](AccumAmDiagGmm& a, const AmDiagGmm& model, Arr<float> x, int i, float w) {
+        return NoGil([&] { return a.AccumulateForGmm(model, x.data(), (size_t)x.size(), i, w); });
+      },
            py::arg("model"), py::arg("data"), py::arg("gmm_index"), py::arg("weight"))
       .def("accumulate_for_gmm_two_feats", [](AccumAmDiagGmm& a, const AmDiagGmm& model, Arr<float> x1, Arr<float> x2, int i, float w) {
-        return a.AccumulateForGmmTwoFeats(model, x1.data(), (size_t)x1.size(), x2.data(), (size_t)x2.size(), i, w);
+        return NoGil([&] { return a.AccumulateForGmmTwoFeats(model, x1.data(), (size_t)x1.size(), x2.data(), (size_t)x2.size(), i, w); });
       }, py::arg("model"), py::arg("data1"), py::arg("data2"), py::arg("gmm_index"), py::arg("weight"))
       .def("accumulate_from_posteriors", [](AccumAmDiagGmm& a, const AmDiagGmm& model, Arr<float> x, int i, Arr<float> post) {
         a.AccumulateFromPosteriors(model, x.data(), (size_t)x.size(), i, post.data(), (size_t)post.size());
-      }, py::arg("model"), py::arg("data"), py::arg("gmm_index"), py::arg("posteriors"))
+      }, py::arg("model"), py::arg("data"), py::arg("gmm_index"), py::arg("weight"))   // the reference names the posterior vector `weight` (mle-am-diag-gmm.cc:31-33)
       .def("accumulate_for_gaussian", [](AccumAmDiagGmm& a, const AmDiagGmm& am, Arr<float> x, int i, int g, float w) {
         a.AccumulateForGaussian(am, x.data(), (size_t)x.size(), i, g, w);
       }, py::arg("am"), py::arg("data"), py::arg("gmm_index"), py::arg("gauss_index"), py::arg("weight"))
@@ -415,7 +437,8 @@ void BindGmm(py::module_& m) {
   m.def("map_am_diag_gmm_update", [](const MapDiagGmmOptions& cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm& am) { return MapAmDiagGmmUpdate(cfg, acc, flags, &am); },
         py::arg("config"), py::arg("amdiag_gmm_acc"), py::arg("flags"), py::arg("am_gmm"));
   m.def("mle_am_diag_gmm_update", [](py::object cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm& am) {
-    const MleUpdateResult r = MleAmDiagGmmUpdate(OptsFrom(cfg), acc, flags, &am);
+    const MleDiagGmmOptions o = OptsFrom(cfg);
+    const MleUpdateResult r = NoGil([&] { return MleAmDiagGmmUpdate(o, acc, flags, &am); });
     return py::make_tuple(r.objf_change, r.count);
   }, py::arg("config"), py::arg("amdiag_gmm_acc"), py::arg("flags"), py::arg("am_gmm"));
 }

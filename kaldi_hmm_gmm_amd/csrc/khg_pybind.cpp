@@ -404,6 +404,7 @@ struct KUtts {
   ~KUtts() { close(); }
   void close() { if (h) { khg_utts_destroy(h); h = nullptr; } }
   void set_pdf_list(Arr<int32_t> p) { Check(khg_utts_set_pdf_list(h, (int32_t)p.shape(0), p.data())); }
+  void features_changed() { Check(khg_utts_features_changed(h)); }
   py::tuple pdf_lists() {
     Arr<int64_t> off({(py::ssize_t)n_utt + 1});
     Check(khg_utts_num_pdfs(h, off.mutable_data()));
@@ -573,7 +574,7 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def_property_readonly("h", [](KUtts& x) { return reinterpret_cast<uintptr_t>(x.h); })
       .def_readonly("ctx", &KUtts::ctx_obj).def_readonly("frame_off", &KUtts::frame_off).def_readonly("n_utt", &KUtts::n_utt)
       .def_readonly("dim", &KUtts::dim)
-      .def("set_pdf_list", &KUtts::set_pdf_list).def("pdf_lists", &KUtts::pdf_lists).def("pdf_first_frames", &KUtts::pdf_first_frames)
+      .def("set_pdf_list", &KUtts::set_pdf_list).def("features_changed", &KUtts::features_changed).def("pdf_lists", &KUtts::pdf_lists).def("pdf_first_frames", &KUtts::pdf_first_frames)
       .def("loglikes", &KUtts::loglikes, py::arg("model"), py::arg("reachable_only") = false)
       .def("loglikes_layout", &KUtts::loglikes_layout).def("download_loglikes", &KUtts::download_loglikes)
       .def("upload_loglikes", &KUtts::upload_loglikes)

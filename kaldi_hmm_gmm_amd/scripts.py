@@ -49,6 +49,14 @@ def gmm_init_mono(topo: HmmTopology, cuts, shared_phones: Optional[List[List[int
     return TransitionModel(ctx_dep=tree, hmm_topo=topo), tree, am
 
 
+def gmm_info(am_gmm: AmDiagGmm, transition_model: TransitionModel) -> Dict[str, int]:
+    """scripts/gmm_info.py:9-29 (the key "feature_dimensition" is spelled as the reference spells it)."""
+    return {"number_of_phones": len(transition_model.phones), "number_of_pdfs": transition_model.num_pdfs,
+            "number_of_transition_ids": transition_model.num_transition_ids,
+            "number_of_transition_states": transition_model.num_transition_states, "feature_dimensition": am_gmm.dim,
+            "number_of_gaussians": am_gmm.num_gauss}
+
+
 def gmm_align_compiled(am_gmm: AmDiagGmm, transition_model: TransitionModel, utt: str, fst: StdVectorFst, feats,
                        align_config: AlignConfig, acoustic_scale: float = 1.0, transition_scale: float = 1.0,
                        self_loop_scale: float = 1.0, num_done: int = 0, num_error: int = 0, num_retried: int = 0,

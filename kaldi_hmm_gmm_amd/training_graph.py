@@ -58,26 +58,44 @@ def generate_hmm_topo(non_sil_phones: List[int], sil_phone: int, num_non_sil_sta
 
 
 class TrainingGraphCompilerOptions:
-    """csrc/training-graph-compiler.h:32-40"""
+    """csrc/training-graph-compiler.h:32-40; python/csrc/training-graph-compiler.cc:17-27 (rm_eps is an attribute, not a
+    constructor argument, there)."""
 
     def __init__(self, transition_scale: float = 1.0, self_loop_scale: float = 1.0, reorder: bool = True):
         self.transition_scale = transition_scale
         self.self_loop_scale = self_loop_scale
+        self.rm_eps = False        # the graphs built here are epsilon-free either way
         self.reorder = reorder
+
+    def __str__(self):
+        return (f"TrainingGraphCompilerOptions(transition_scale={self.transition_scale}, self_loop_scale={self.self_loop_scale}, "
+                f"rm_eps={self.rm_eps}, reorder={self.reorder})")
 
 
 class TrainingGraphCompiler:
-    """``lexicon``: word-id -> list of (probability, [phone ids]) pronunciations (scripts/prepare_lang.py
-    Lexiconp).  ``sil_phone`` != None adds the optional silence of make_lexicon_fst_with_silence
-    (before the first word and after every word, probability ``sil_prob``)."""
+    """python/csrc/training-graph-compiler.cc:32-58: ``TrainingGraphCompiler(trans_model, ctx_dep, lex_fst, disambig_syms, opts)``.
 
-    def __init__(self, trans_model, ctx_dep, lexicon: Dict[int, List[Tuple[float, List[int]]]], sil_phone: Optional[int] = None,
-                 sil_prob: float = 0.5, opts: Optional[TrainingGraphCompilerOptions] = None):
+    ``lex_fst`` is the lexicon, in one of two forms:
+      * an ``StdVectorFst`` L (input labels = phones, output labels = words; scripts/prepare_lang.py:329-456 writes it) -- input
+        labels listed in ``disambig_syms`` are treated as epsilons, like the reference's graph compilation removes them;
+      * a dict word-id -> list of (probability, [phone ids]) pronunciations (scripts/prepare_lang.py Lexiconp); then
+        ``sil_phone`` != None adds the optional silence of make_lexicon_fst_with_silence (before the first word and after
+        every word, probability ``sil_prob``).
+    """
+
+    def __init__(self, trans_model, ctx_dep, lex_fst, disambig_syms: Optional[Sequence[int]] = None,
+                 opts: Optional[TrainingGraphCompilerOptions] = None, *, sil_phone: Optional[int] = None, sil_prob: float = 0.5):
         if ctx_dep.context_width != 1 or ctx_dep.central_position != 0:
             raise KhgError("TrainingGraphCompiler: only monophone context (N=1, P=0) is supported")
         self.tm = trans_model
         self.ctx_dep = ctx_dep
-        self.lexicon = lexicon
+        if isinstance(lex_fst, dict):
+            self.lexicon, self.lex_fst = lex_fst, None
+        else:
+            self.lexicon, self.lex_fst = None, lex_fst.copy()       # the reference's binding copies too (lex_fst->Copy())
+            if sil_phone is not None:
+                raise KhgError("TrainingGraphCompiler: sil_phone belongs to the dict form; an L.fst carries its own silence arcs")
+        self.disambig_syms = sorted(int(x) for x in (disambig_syms or []))
         self.sil_phone = sil_phone
         self.sil_prob = float(sil_prob)
         self.opts = opts or TrainingGraphCompilerOptions()
@@ -178,8 +196,96 @@ class TrainingGraphCompiler:
         start_final = no_sil_cost if n == 0 else None
         return nodes, arcs, loop[n], start, start_final
 
+    # ---- the same from an L.fst: L o (linear acceptor of the transcript), input epsilons / disambiguation symbols removed ----
+    def _phone_graph_from_lfst(self, transcript: Sequence[int]):
+        """-> (num_nodes, arcs[(src, dst, phone, olabel, cost)], finals{node: cost}, start).  Product of the lexicon FST with the
+        word positions 0..n: an arc with output label 0 moves in L only, an arc whose output label is the next word moves in
+        both (csrc/training-graph-compiler.cc:74-96 composes L with the transcript's linear acceptor); then every arc whose
+        input label is 0 or a disambiguation symbol is folded into its successors (tropical epsilon removal)."""
+        L, n = self.lex_fst, len(transcript)
+        if L.start < 0:
+            raise KhgError("TrainingGraphCompiler: empty lexicon FST")
+        dis = set(self.disambig_syms)
+        index, order = {}, []
+
+        def get(ls, k):
+            if (ls, k) not in index:
+                index[(ls, k)] = len(order)
+                order.append((ls, k))
+            return index[(ls, k)]
+
+        get(L.start, 0)
+        raw = []                       # (src, dst, phone (0 = epsilon), olabel, cost)
+        finals = {}
+        i = 0
+        while i < len(order):
+            ls, k = order[i]
+            src = i
+            i += 1
+            if k == n and L.is_final(ls):
+                finals[src] = float(L.final(ls))
+            for a in L.arcs(ls):
+                ph = 0 if (a.ilabel == 0 or a.ilabel in dis) else a.ilabel
+                if a.olabel == 0 or a.olabel in dis:
+                    raw.append((src, get(a.nextstate, k), ph, 0, float(a.weight)))
+                elif k < n and a.olabel == transcript[k]:
+                    raw.append((src, get(a.nextstate, k + 1), ph, a.olabel, float(a.weight)))
+        nodes = len(order)
+        # epsilon removal: eps-closure (cheapest cost, at most one word label) of every node, then re-emit the closure's real arcs
+        out = [[] for _ in range(nodes)]
+        for r in raw:
+            out[r[0]].append(r)
+        arcs, new_finals = [], {}
+        for s0 in range(nodes):
+            best = {s0: (0.0, 0)}      # node -> (cost, carried olabel)
+            stack = [s0]
+            while stack:
+                s = stack.pop()
+                c, ol = best[s]
+                for (_, d, ph, ol2, w) in out[s]:
+                    if ph != 0:
+                        continue
+                    if ol and ol2:
+                        raise KhgError("TrainingGraphCompiler: two word labels on one chain of epsilon arcs of the lexicon FST")
+                    v = (c + w, ol or ol2)
+                    if d not in best or v[0] < best[d][0]:
+                        best[d] = v
+                        stack.append(d)
+            for s, (c, ol) in best.items():
+                if s in finals:
+                    if ol:
+                        raise KhgError("TrainingGraphCompiler: a word label on an epsilon arc into a final state of the lexicon FST")
+                    v = c + finals[s]
+                    if s0 not in new_finals or v < new_finals[s0]:
+                        new_finals[s0] = v
+                for (_, d, ph, ol2, w) in out[s]:
+                    if ph == 0:
+                        continue
+                    if ol and ol2:
+                        raise KhgError("TrainingGraphCompiler: a word label on an epsilon arc before a labelled phone arc")
+                    arcs.append((s0, d, ph, ol or ol2, c + w))
+        # keep what the start can reach (nodes that were only reachable through epsilons are now dead)
+        reach, stack = {0}, [0]
+        by_src = {}
+        for a in arcs:
+            by_src.setdefault(a[0], []).append(a)
+        while stack:
+            s = stack.pop()
+            for a in by_src.get(s, []):
+                if a[1] not in reach:
+                    reach.add(a[1])
+                    stack.append(a[1])
+        arcs = [a for a in arcs if a[0] in reach]
+        new_finals = {s: c for s, c in new_finals.items() if s in reach}
+        return nodes, arcs, new_finals, 0
+
     def compile_graph_from_text(self, transcript: Sequence[int]) -> StdVectorFst:
         """csrc/training-graph-compiler.cc:65-141 for a linear word sequence."""
+        if self.lex_fst is not None:
+            nodes, parcs, finals, start = self._phone_graph_from_lfst([int(w) for w in transcript])
+            if not finals:
+                raise KhgError("succeeded assertion failed: the lexicon FST does not accept the transcript")   # KHG_ASSERT(succeeded)
+            return self._expand(nodes, parcs, finals, start)
         nodes, parcs, final_node, start, start_final = self._phone_graph(list(transcript))
         finals = {final_node: 0.0}
         if start_final is not None:
@@ -192,6 +298,8 @@ class TrainingGraphCompiler:
         G = a one-state unigram, built with the same expansion as the training graphs (transition-ids on the
         input side, word-ids on the output side, "reorder" self-loops, epsilon-free).  What egs/yesno/decode.py
         decodes with (there: HLG from the lang directory)."""
+        if self.lexicon is None:
+            raise KhgError("compile_word_loop_graph: needs the dict form of the lexicon")
         words = sorted(self.lexicon)
         if not words:
             raise KhgError("compile_word_loop_graph: empty lexicon")
@@ -292,13 +400,51 @@ class TrainingGraphCompiler:
         return [self.compile_graph_from_text(t) for t in transcripts]
 
 
-def equal_align(fst: StdVectorFst, length: int, rand_seed: int = 3, num_retries: int = 10):
+def make_lexicon_fst_with_silence(lexicon: Dict[int, List[Tuple[float, List[int]]]], sil_phone: int, sil_prob: float = 0.5,
+                                  sil_disambig: Optional[int] = None) -> StdVectorFst:
+    """The lexicon FST L of scripts/prepare_lang.py:329-456 over integer ids: ``lexicon`` maps word-id -> [(probability, [phone
+    ids, possibly ending in a disambiguation symbol id])].  State 0 = start, 1 = loop (final), 2 = silence; the optional silence
+    (probability ``sil_prob``) sits before the first word and after every word.  What egs/yesno/train.py:58-63 hands to
+    TrainingGraphCompiler as ``lex_fst``."""
+    sil_cost = -math.log(sil_prob)
+    no_sil_cost = -math.log(1.0 - sil_prob)
+    fst = StdVectorFst()
+    start_state, loop_state, sil_state = fst.add_state(), fst.add_state(), fst.add_state()
+    fst.start = start_state
+    fst.set_final(state=loop_state, weight=0)
+    fst.add_arc(state=start_state, arc=StdArc(ilabel=0, olabel=0, weight=no_sil_cost, nextstate=loop_state))
+    fst.add_arc(state=start_state, arc=StdArc(ilabel=0, olabel=0, weight=sil_cost, nextstate=sil_state))
+    if sil_disambig is None:
+        fst.add_arc(state=sil_state, arc=StdArc(ilabel=sil_phone, olabel=0, weight=0, nextstate=loop_state))
+    else:
+        d = fst.add_state()
+        fst.add_arc(state=sil_state, arc=StdArc(ilabel=sil_phone, olabel=0, weight=0, nextstate=d))
+        fst.add_arc(state=d, arc=StdArc(ilabel=sil_disambig, olabel=0, weight=0, nextstate=loop_state))
+    for word in lexicon:
+        for prob, phones in lexicon[word]:
+            pron_cost = -math.log(float(prob))
+            cur = loop_state
+            for i in range(len(phones) - 1):
+                nxt = fst.add_state()
+                fst.add_arc(state=cur, arc=StdArc(ilabel=phones[i], olabel=word if i == 0 else 0, weight=pron_cost if i == 0 else 0, nextstate=nxt))
+                cur = nxt
+            i = len(phones) - 1                    # -1 for an empty pronunciation
+            il = phones[i] if i >= 0 else 0
+            ol = word if i <= 0 else 0
+            w = pron_cost if i <= 0 else 0
+            fst.add_arc(state=cur, arc=StdArc(ilabel=il, olabel=ol, weight=no_sil_cost + w, nextstate=loop_state))
+            fst.add_arc(state=cur, arc=StdArc(ilabel=il, olabel=ol, weight=sil_cost + w, nextstate=sil_state))
+    return fst
+
+
+def equal_align(ifst: StdVectorFst, length: int, rand_seed: int = 3, num_retries: int = 10):
     """Kaldi EqualAlign as used through kaldifst.equal_align (egs/yesno/train.py:86-108): a random
     path from the start to a final state, then the remaining frames spread as evenly as possible
     over the self-loops on that path.  Returns (ok, alignment) -- alignment = list of ``length``
     ilabels.  Only the contract is pinned by the reference (a valid path of exactly ``length``
     transition-ids, scripts/test_training_graph_compiler.py:85-105); the random choices come from a
     numpy Generator seeded with ``rand_seed`` instead of libc rand()."""
+    fst = ifst        # (kaldifst.equal_align's keyword, egs/yesno/train.py:88-93)
     if fst.start < 0:
         return False, []
     rng = np.random.default_rng(rand_seed)

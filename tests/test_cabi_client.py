@@ -14,8 +14,13 @@ HOST_BIN = os.path.join(ROOT, "tests", "_build", "host_client")
 
 def _build():
     import __graft_entry__ as g
-    stale = lambda b, src: not os.path.exists(b) or os.path.getmtime(b) < os.path.getmtime(os.path.join(ROOT, "tests", src))      # noqa: E731
-    if stale(BIN, "cabi_client.c") or stale(HOST_BIN, "host_client.cpp"):
+    csrc = os.path.join(ROOT, "kaldi_hmm_gmm_amd", "csrc")
+    hdr = os.path.join(ROOT, "include", "khg_hip.h")
+    host = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.startswith("khg_host_") and f.endswith((".cpp", ".hpp"))]
+
+    def stale(b, srcs):         # the binaries compile the host classes in: an edit to any of them (or to the header) rebuilds
+        return not os.path.exists(b) or any(os.path.getmtime(b) < os.path.getmtime(s) for s in srcs)
+    if stale(BIN, [os.path.join(ROOT, "tests", "cabi_client.c"), hdr]) or stale(HOST_BIN, [os.path.join(ROOT, "tests", "host_client.cpp"), hdr] + host):
         g.build()
     assert os.path.exists(BIN) and os.path.exists(HOST_BIN)
 

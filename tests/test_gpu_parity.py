@@ -760,3 +760,64 @@ def test_reference_stored_logsumexp_softmax_vectors_through_k1_and_k3(ctx):
     assert np.abs(st["occ"] - np.asarray(SOFTMAX_EXPECTED)).max() < 1e-4
     post, lse = orc.softmax(SOFTMAX_V)
     assert np.abs(st["occ"] - post).max() <= 2e-7 and abs(st["total_log_like"] - lse) <= 2e-6
+
+
+def test_set_pdf_list_twice_on_one_set(ctx, k1_form):
+    """khg_utts_set_pdf_list called again on the same set -- first a short list, then a LONGER one with other pdfs -- must score the
+    new list: every per-set cache derived from the old list (tile walk lists, the default form's unit table, the id range check) is
+    dropped.  A pdf id outside the model is an error the second time too."""
+    from kaldi_hmm_gmm_amd import DeviceModel, KhgError, UtteranceSet
+
+    P, G, D = 40, 64, 40
+    m, gc, om, ut, cost = build(P, G, D, n_utt=2, seed=77)
+    lens = np.array([33, 200, 64, 7])
+    frame_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rng = np.random.default_rng(5)
+    feats = (rng.standard_normal((int(frame_off[-1]), D)) * 1.5 + 0.3).astype(np.float32)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    us = UtteranceSet(ctx, None, frame_off, feats)
+    for pl in (np.array([3, 9, 17], np.int32), np.array([0, 1, 2, 5, 8, 13, 21, 22, 34, 39], np.int32), np.array([38], np.int32)):
+        us.set_pdf_list(pl)
+        us.loglikes(dm)
+        got = us.download_loglikes()
+        for u in range(len(lens)):
+            x = feats[frame_off[u]: frame_off[u + 1]]
+            exact, bound = exact_loglikes(m, gc, x, pl)
+            assert got[u].shape == exact.shape
+            assert (np.abs(got[u] - exact) <= LL_ATOL + LL_RTOL * bound).all(), f"list {pl.tolist()} utt {u}"
+    us.set_pdf_list(np.array([1, P], np.int32))
+    with pytest.raises(KhgError):
+        us.loglikes(dm)
+    us.close()
+
+
+def test_features_changed_repacks_the_planes(ctx, opt):
+    """Borrowed device features rewritten in place + khg_utts_features_changed: the default K1 (fp16 planes packed once per set)
+    scores the NEW features."""
+    import torch
+
+    from kaldi_hmm_gmm_amd import DeviceModel, UtteranceSet
+
+    opt.k1("f16x2s")
+    P, G, D = 12, 64, 40
+    m, gc, om, ut, cost = build(P, G, D, n_utt=2, seed=78)
+    frame_off = np.array([0, 100, 164], np.int64)
+    rng = np.random.default_rng(6)
+    f1 = (rng.standard_normal((164, D)) * 1.5).astype(np.float32)
+    f2 = (rng.standard_normal((164, D)) * 2.5 + 1.0).astype(np.float32)
+    buf = torch.from_numpy(f1).cuda()
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    us = UtteranceSet(ctx, None, frame_off, (buf.data_ptr(), buf), dim=D)
+    pl = np.arange(P, dtype=np.int32)
+    us.set_pdf_list(pl)
+    for f in (f1, f2):
+        buf.copy_(torch.from_numpy(f))
+        torch.cuda.synchronize()
+        us.features_changed()
+        us.loglikes(dm)
+        got = us.download_loglikes()
+        for u in range(2):
+            x = f[frame_off[u]: frame_off[u + 1]]
+            exact, bound = exact_loglikes(m, gc, x, pl)
+            assert (np.abs(got[u] - exact) <= LL_ATOL + LL_RTOL * bound).all()
+    us.close()

@@ -146,3 +146,28 @@ def test_dimension_limit_is_an_error(ctx):
     go = np.array([0, 1, 2], np.int32)
     with pytest.raises(KhgError, match="feature dim > 512"):
         DeviceModel(ctx, go, np.zeros(2, np.float32), np.zeros((2, D), np.float32), np.ones((2, D), np.float32))
+
+
+def test_wide_loglikes_tolerate_an_infinite_first_gconst(ctx):
+    """A zero-weight FIRST component (gconst = log 0 = -inf, which ComputeGconsts keeps: csrc/diag-gmm.cc:132-146) must not poison
+    the online log-sum-exp of the D > 80 kernel: the pdf's log-likelihood is the log-sum over the other components."""
+    from kaldi_hmm_gmm_amd import DeviceModel, UtteranceSet
+
+    P, G, D = 3, 5, 96
+    m, gc, om, ut, cost = build(P, G, D, n_utt=2, seed=91)
+    gc = gc.copy()
+    gc[int(m.gauss_off[1])] = -np.inf              # pdf 1: first component dead
+    gc[int(m.gauss_off[2]) + 2] = -np.inf          # pdf 2: a middle one
+    frame_off = np.array([0, 70], np.int64)
+    feats = (np.random.default_rng(3).standard_normal((70, D)) * 1.5).astype(np.float32)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    us = UtteranceSet(ctx, None, frame_off, feats)
+    pl = np.arange(P, dtype=np.int32)
+    us.set_pdf_list(pl)
+    us.loglikes(dm)
+    got = us.download_loglikes()[0]
+    with np.errstate(invalid="ignore"):
+        exact, bound = exact_loglikes(m, np.where(np.isinf(gc), -1e30, gc).astype(np.float64), feats, pl)
+    assert np.isfinite(got).all()
+    assert (np.abs(got - exact) <= LL_ATOL + LL_RTOL * np.minimum(bound, 1e6) * 2).all()
+    us.close()

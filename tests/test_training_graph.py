@@ -190,3 +190,32 @@ def test_word_loop_decoding_graph_accepts_what_training_graphs_accept():
         cur = nxt
     finals = [(c + loop.final(s), w) for s, (c, w) in cur.items() if loop.is_final(s)]
     assert min(finals)[1] == [2, 3, 1]
+
+
+@pytest.mark.parametrize("sil_disambig", [None, 9])
+def test_lexicon_fst_form_equals_dict_form(sil_disambig):
+    """TrainingGraphCompiler(trans_model=, ctx_dep=, lex_fst=, disambig_syms=, opts=) -- the reference's constructor
+    (python/csrc/training-graph-compiler.cc:32-58, egs/yesno/train.py:70-76) with an L.fst built like
+    scripts/prepare_lang.py:329-456 -- accepts the same transition-id sequences at the same costs as the dict form."""
+    from kaldi_hmm_gmm_amd import TrainingGraphCompiler, TrainingGraphCompilerOptions, equal_align, make_lexicon_fst_with_silence
+
+    topo, cd, tm, gc_dict = _setup(True)
+    lex = {1: [(1.0, [2])], 2: [(1.0, [3])], 3: [(0.7, [2, 4]), (0.3, [4, 8])]}       # 8 = a disambiguation symbol (#1) on one pronunciation
+    L = make_lexicon_fst_with_silence(lex, sil_phone=1, sil_prob=0.5, sil_disambig=sil_disambig)
+    gc = TrainingGraphCompiler(trans_model=tm, ctx_dep=cd, lex_fst=L, disambig_syms=[7, 8, 9], opts=TrainingGraphCompilerOptions())
+    assert L.num_states == gc.lex_fst.num_states            # the compiler works on its own copy
+    for seed, words in enumerate([[1], [1, 2], [2, 3, 1], [3, 3], []]):
+        a, b = gc_dict.compile_graph_from_text(words), gc.compile_graph_from_text(word_ids := list(words))
+        for s in range(b.num_states):
+            assert all(x.ilabel != 0 for x in b.arcs(s)), "the compiled graph must be epsilon-free"
+        for T in (40, 61):
+            for g_src, g_other in ((a, b), (b, a)):
+                ok, ali = equal_align(ifst=g_src, length=T, rand_seed=seed + 3, num_retries=10)
+                if not words:
+                    continue
+                assert ok
+                ca, cb = _walk(g_src, ali), _walk(g_other, ali)
+                assert cb is not None and abs(ca - cb) < 1e-4, (words, ca, cb)
+        assert word_ids == list(words)
+    with pytest.raises(Exception):
+        gc.compile_graph_from_text([5])                      # a word the lexicon FST does not have
