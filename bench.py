@@ -112,7 +112,7 @@ def pmc_traffic(frames_per_launch, k1_form="f16x2s"):
     return None, "no PMC summary under profiles/"
 
 
-def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
+def cpu_baseline(model, gc, ut, cost, feats_host, budget_s, beam=200.0, retry_beam=0.0):
     """The oracle (CPU restatement, kind="port") timed on a bounded sample of the SAME workload:
     AlignUtteranceWrapper + acc-stats per utterance, one thread -- the reference's execution model."""
     from oracle import oracle as orc
@@ -122,12 +122,17 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[g["ilabel"]], g["weight"]).astype(np.float32)
     nmax = feats_host["n"]
 
+    kept = {"ali": [], "status": [], "like": []}          # the oracle's answers, for the parity check at this scale (check_vs_oracle)
+
     def one(u, oa):
         og = orc.OGraph.from_set(g, u)
         f = feats_host["feats"][ut.frame_off[u]: ut.frame_off[u + 1]]
-        r = orc.align_utterance(og, om, model.id2pdf, f, acoustic_scale=0.1)
-        if (r["status"] & 1) == 0:
+        r = orc.align_utterance(og, om, model.id2pdf, f, acoustic_scale=0.1, beam=beam, retry_beam=retry_beam)
+        ok = (r["status"] & 1) == 0
+        if ok:
             orc.acc_stats_ali(om, model.id2pdf, f, r["ali"], oa)
+        kept["ali"].append(np.asarray(r["ali"], np.int32) if ok else np.zeros(f.shape[0], np.int32))
+        kept["status"].append(int(r["status"])); kept["like"].append(np.float32(r["like"]) if ok else np.float32(0))
         return f.shape[0]
 
     # (A) one thread: the reference's execution model (its scripts loop over utterances in Python), built with the
@@ -168,19 +173,84 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s):
     nthr = max(1, min(ncpu, quota, mem_cap, 512))
     if os.environ.get("KHG_BENCH_CPU_THREADS"):
         nthr = max(1, int(os.environ["KHG_BENCH_CPU_THREADS"]))
+    keep_b = {}
     fr, nn, failed, dtb = orc.em_pass_mt(om, model.id2pdf, g, ut.frame_off, feats_host["feats"], first_utt=n1, n_utt=max(nmax - n1, 0),
-                                         num_threads=nthr, budget_seconds=budget_s / 2, acoustic_scale=0.1)
+                                         num_threads=nthr, budget_seconds=budget_s / 2, acoustic_scale=0.1, beam=beam, retry_beam=retry_beam,
+                                         keep=keep_b)
     done = [fr, nn]
     orc.use(None)
+    # what both legs computed, as one answer over utterances [0, n1 + nn): alignments, status, like, accumulators (A + B)
+    nb_fr = int(ut.frame_off[n1 + nn] - ut.frame_off[n1])
+    ob = keep_b["accs"]
+    oracle_answer = {"n_utt": n1 + nn,
+                     "ali": np.concatenate(kept["ali"] + [keep_b["ali"][:nb_fr]]) if (n1 + nn) else np.zeros(0, np.int32),
+                     "status": np.concatenate([np.asarray(kept["status"], np.int32), keep_b["status"][:nn]]),
+                     "like": np.concatenate([np.asarray(kept["like"], np.float32), keep_b["like"][:nn]]),
+                     "occ": oa.occ + ob.occ, "mean_acc": oa.mean_acc + ob.mean_acc, "var_acc": oa.var_acc + ob.var_acc,
+                     "trans_acc": oa.trans_acc + ob.trans_acc, "total_frames": oa.total_frames + ob.total_frames,
+                     "total_log_like": oa.total_log_like + ob.total_log_like}
     par = done[0] / dtb if done[1] else 0.0
     one_thr = frames1 / dt1
     best, cores = (par, nthr) if par > one_thr else (one_thr, 1)
-    return {"value": best, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread_value": one_thr,
+    return oracle_answer, {"value": best, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread_value": one_thr,
             "sample": f"oracle/khg_oracle.c: FasterDecoder + GMM decodable + acc-stats per utterance of rank 0's shard; "
                       f"1 thread (gcc -O3, the reference's default flags): first {n1} utterances ({frames1} frames) in {dt1:.1f}s; "
                       f"{nthr} POSIX threads inside the C oracle ({ncpu} logical CPUs visible, CPU quota {quota}; gcc -O3 -march=native, "
                       f"utterance-parallel, private accumulators): "
                       f"next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
+
+
+def check_vs_oracle(ans, ut, feats, D, sets, ctx, dm, tm, args):
+    """Parity at the benchmark's scale, after the timed region: the product's alignment of the utterances the CPU baseline
+    just aligned (K1 + K2 once more with the results downloaded) against the oracle's, utterance by utterance, and K3 over exactly
+    those utterances against the oracle's accumulators (tolerances of tests/test_gpu_parity.py: rtol 2e-5)."""
+    from kaldi_hmm_gmm_amd import DeviceAccs, UtteranceSet
+
+    n = int(ans["n_utt"])
+    if n == 0:
+        return {"oracle_utts": 0}
+    nfr = int(ut.frame_off[n])
+    got_ali, got_status, got_like = [], [], []
+    for s_ in sets:                                   # the sets cover the shard in utterance order
+        if sum(len(x) for x in got_status) >= n:
+            break
+        s_.loglikes(dm, reachable_only=not args.full_loglikes)
+        r = s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=True)
+        got_ali.append(np.asarray(r["ali"])); got_status.append(np.asarray(r["status"])); got_like.append(np.asarray(r["like"]))
+    g_ali = np.concatenate(got_ali)[:nfr]; g_status = np.concatenate(got_status)[:n]; g_like = np.concatenate(got_like)[:n]
+    o_ali, o_status, o_like = ans["ali"][:nfr], ans["status"][:n], ans["like"][:n]
+    neq = g_ali != o_ali
+    bad_utts = np.add.reduceat(neq.astype(np.int64), ut.frame_off[:n].astype(np.int64)) > 0 if nfr else np.zeros(n, bool)
+    bad_utts &= np.diff(ut.frame_off[: n + 1]) > 0
+    status_mismatch = int((((g_status & 1) != 0) != ((o_status & 1) != 0)).sum() + (((g_status & 2) != 0) != ((o_status & 2) != 0)).sum())
+    okm = ((g_status & 1) == 0) & ((o_status & 1) == 0)
+    like_rel = float(np.max(np.abs(g_like[okm] - o_like[okm]) / np.maximum(np.abs(o_like[okm]), 1.0))) if okm.any() else 0.0
+    # K3 on exactly those utterances, from the ORACLE's alignment (so that a decoder difference cannot hide in the statistics)
+    sub = UtteranceSet(ctx, None, ut.frame_off[: n + 1].astype(np.int64), (feats.data_ptr(), feats), dim=D)
+    sub.upload_ali(np.ascontiguousarray(o_ali, np.int32))
+    acc2 = DeviceAccs(ctx, dm, tm)
+    sub.acc_stats(dm, tm, acc2)
+    got = acc2.download()
+    sub.close(); acc2.close()
+
+    def rel(a, b, atol):
+        return float(np.max(np.abs(a - b) / (np.abs(b) + atol)))
+    mmax, vmax = float(np.abs(ans["mean_acc"]).max()), float(np.abs(ans["var_acc"]).max())
+    e_occ, e_mean, e_var = rel(got["occ"], ans["occ"], 1e-6 / 2e-5), rel(got["mean_acc"], ans["mean_acc"], 2e-6 * mmax / 2e-5), \
+        rel(got["var_acc"], ans["var_acc"], 2e-6 * vmax / 2e-5)
+    return {"oracle_utts": n, "oracle_frames": nfr, "ali_mismatch_utts": int(bad_utts.sum()), "ali_mismatch_frames": int(neq.sum()),
+            "status_mismatch": status_mismatch, "oracle_failed_utts": int(((o_status & 1) != 0).sum()),
+            "like_max_rel_err": like_rel,
+            "max_rel_err_occ": e_occ, "max_rel_err_mean_acc": e_mean, "max_rel_err_var_acc": e_var,
+            "trans_acc_equal": bool(np.array_equal(got["trans_acc"], ans["trans_acc"])),
+            "stats_within_2e-5": bool(max(e_occ, e_mean, e_var) <= 2e-5),
+            "total_frames_equal": bool(got["total_frames"] == ans["total_frames"]),
+            "avg_loglike_per_frame_oracle": ans["total_log_like"] / max(ans["total_frames"], 1.0),
+            "avg_loglike_per_frame_k3": got["total_log_like"] / max(got["total_frames"], 1.0),
+            "note": "after the timed region: the utterances bench.py's cpu_baseline aligned with oracle/khg_oracle.c (FasterDecoder + GMM "
+                    "decodable + acc-stats) against K1 + K2 (alignment, status, like per utterance) and K3 (statistics of those utterances "
+                    "from the oracle's alignment); max_rel_err_* = max |got - want| / (|want| + atol) with the atol of tests/test_gpu_parity.py "
+                    "folded in (<= 2e-5 passes)"}
 
 
 def main():
@@ -609,7 +679,10 @@ def main():
         if not args.no_cpu_baseline:               # rank 0, whatever N (the other ranks wait at the closing barrier)
             ncpu = min(n_local, 40000)     # enough work for a few seconds of every host core
             fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds)
+            ans, out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds,
+                                                    beam=args.beam, retry_beam=args.retry_beam)
+            # the oracle's alignments and accumulators of that sample against the product's, at the benchmark's own shape
+            out["check"].update(check_vs_oracle(ans, ut, feats, D, sets, ctxs[0], dm, tm, args))
         else:
             out["cpu_baseline"] = None
         record = json.dumps(out)

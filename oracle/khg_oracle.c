@@ -1281,6 +1281,11 @@ typedef struct {
   int32_t ready_count, go;
   int64_t frames_done; int32_t utts_done; int32_t failed;
   double t_end;                /* when the last thread finished its last utterance */
+  /* optional: what the pass computed, kept for parity checks at scale (bench.py `check`) -- written outside the timed work */
+  int32_t *ali_out;            /* [frame_off[first_utt + n_utt] - frame_off[first_utt]] transition-ids, 0 on failed utterances */
+  int32_t *status_out;         /* [n_utt] ORC_ALIGN_* bits, -1 = not reached within the budget */
+  float *like_out;             /* [n_utt] */
+  orc_accs *acc_sum;           /* the threads' private accumulators summed (in thread-finish order) */
 } orc_mt_job;
 
 static double mt_elapsed(const struct timespec *t0) {
@@ -1335,11 +1340,27 @@ static void *mt_worker(void *arg) {
       } else {
         ++failed;
       }
+      if (j->status_out) j->status_out[u - j->first_utt] = rc == ORC_OK ? status : (ORC_ALIGN_ERROR | 0x4000);
+      if (j->like_out) j->like_out[u - j->first_utt] = like;
+      if (j->ali_out && T > 0) {
+        int32_t *dst = j->ali_out + (j->frame_off[u] - j->frame_off[j->first_utt]);
+        if (rc == ORC_OK && (status & ORC_ALIGN_ERROR) == 0) memcpy(dst, ali, sizeof(int32_t) * (size_t)T);
+        else memset(dst, 0, sizeof(int32_t) * (size_t)T);
+      }
       frames += T; ++utts;
       free(loc); free(ali); free(words);
     }
   }
   const double t_end = mt_elapsed(&j->t0);
+  pthread_mutex_lock(&j->mu);
+  if (have && j->acc_sum) {    /* after the clock: the cross-thread sum (AccumAmDiagGmm::Add, mle-am-diag-gmm.cc:119-128) */
+    orc_accs *s = j->acc_sum;
+    for (int64_t i = 0; i < sumG; ++i) s->occ[i] += acc.occ[i];
+    for (int64_t i = 0; i < sumG * m->dim; ++i) { s->mean_acc[i] += acc.mean_acc[i]; s->var_acc[i] += acc.var_acc[i]; }
+    for (int32_t i = 0; i <= j->num_tids; ++i) s->trans_acc[i] += acc.trans_acc[i];
+    s->total_frames += acc.total_frames; s->total_log_like += acc.total_log_like;
+  }
+  pthread_mutex_unlock(&j->mu);
   free(acc.occ); free(acc.mean_acc); free(acc.var_acc); free(acc.trans_acc);
   pthread_mutex_lock(&j->mu);
   j->frames_done += frames; j->utts_done += utts; j->failed += failed;
@@ -1353,9 +1374,22 @@ int orc_em_pass_mt(const orc_align_config *cfg, float acoustic_scale, const orc_
                    const int32_t *start, const int64_t *arc_off, const int32_t *ilabel, const int32_t *olabel,
                    const float *weight, const int32_t *nextstate, const float *final, int32_t num_threads,
                    double budget_seconds, int64_t *frames_done, int32_t *utts_done, int32_t *failed, double *seconds) {
+  return orc_em_pass_mt_keep(cfg, acoustic_scale, m, id2pdf, num_tids, first_utt, n_utt, frame_off, feats, state_off, start, arc_off, ilabel,
+                             olabel, weight, nextstate, final, num_threads, budget_seconds, frames_done, utts_done, failed, seconds, NULL,
+                             NULL, NULL, NULL);
+}
+
+int orc_em_pass_mt_keep(const orc_align_config *cfg, float acoustic_scale, const orc_model *m, const int32_t *id2pdf, int32_t num_tids,
+                        int32_t first_utt, int32_t n_utt, const int64_t *frame_off, const float *feats, const int64_t *state_off,
+                        const int32_t *start, const int64_t *arc_off, const int32_t *ilabel, const int32_t *olabel,
+                        const float *weight, const int32_t *nextstate, const float *final, int32_t num_threads,
+                        double budget_seconds, int64_t *frames_done, int32_t *utts_done, int32_t *failed, double *seconds,
+                        int32_t *ali_out, int32_t *status_out, float *like_out, orc_accs *acc_sum) {
   if (num_threads < 1 || n_utt < 0) return ORC_ERR_ARG;
   orc_mt_job j;
   memset(&j, 0, sizeof(j));
+  j.ali_out = ali_out; j.status_out = status_out; j.like_out = like_out; j.acc_sum = acc_sum;
+  if (status_out) for (int32_t i = 0; i < n_utt; ++i) status_out[i] = -1;
   j.cfg = cfg; j.acoustic_scale = acoustic_scale; j.m = m; j.id2pdf = id2pdf; j.num_tids = num_tids;
   j.first_utt = first_utt; j.n_utt = n_utt; j.frame_off = frame_off; j.state_off = state_off; j.arc_off = arc_off;
   j.start = start; j.ilabel = ilabel; j.olabel = olabel; j.nextstate = nextstate; j.weight = weight; j.final = final; j.feats = feats;

@@ -229,6 +229,18 @@ int orc_em_pass_mt(const orc_align_config *cfg, float acoustic_scale, const orc_
                    const int32_t *olabel, const float *weight, const int32_t *nextstate,
                    const float *final, int32_t num_threads, double budget_seconds,
                    int64_t *frames_done, int32_t *utts_done, int32_t *failed, double *seconds);
+/* the same pass, keeping what it computed (any of the four may be NULL): alignments (0 on failed utterances; positioned by
+ * frame_off relative to first_utt), per-utterance status (-1 = not reached within the budget; the reached utterances are a
+ * prefix) and like, and the sum of the threads' accumulators (caller-allocated, zeroed) -- the oracle's answer for a parity
+ * check at the benchmark's own scale */
+int orc_em_pass_mt_keep(const orc_align_config *cfg, float acoustic_scale, const orc_model *m,
+                        const int32_t *id2pdf, int32_t num_tids, int32_t first_utt, int32_t n_utt,
+                        const int64_t *frame_off, const float *feats, const int64_t *state_off,
+                        const int32_t *start, const int64_t *arc_off, const int32_t *ilabel,
+                        const int32_t *olabel, const float *weight, const int32_t *nextstate,
+                        const float *final, int32_t num_threads, double budget_seconds,
+                        int64_t *frames_done, int32_t *utts_done, int32_t *failed, double *seconds,
+                        int32_t *ali_out, int32_t *status_out, float *like_out, orc_accs *acc_sum);
 
 #ifdef __cplusplus
 }

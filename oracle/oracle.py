@@ -312,10 +312,12 @@ def acc_stats_ali(m: OModel, id2pdf, feats, ali, accs: OAccs, weight=1.0):
 
 
 def em_pass_mt(m: "OModel", id2pdf, graphs: dict, frame_off, feats, first_utt=0, n_utt=None, num_threads=1, budget_seconds=1e9,
-               acoustic_scale=1.0, beam=200.0, retry_beam=0.0, **kw):
+               acoustic_scale=1.0, beam=200.0, retry_beam=0.0, keep=None, **kw):
     """orc_em_pass_mt: align + acc-stats per utterance on `num_threads` POSIX threads (bench.py's cpu_baseline, variant B).
     `graphs` is the concatenated CSR dict of the utterance set (weights already carrying the transition costs).
-    -> (frames_done, utterances_done, failed, seconds)"""
+    -> (frames_done, utterances_done, failed, seconds).  With keep = a dict, what the pass computed is left in it: "ali" (int32 per
+    frame of the utterances handed in, 0 where an utterance failed or was not reached), "status" (-1 = not reached; the reached
+    utterances are a prefix), "like", and "accs" (an OAccs: the threads' accumulators summed)."""
     id2pdf = np.ascontiguousarray(id2pdf, np.int32)
     fo = np.ascontiguousarray(frame_off, np.int64)
     x = np.ascontiguousarray(feats, f32)
@@ -326,13 +328,25 @@ def em_pass_mt(m: "OModel", id2pdf, graphs: dict, frame_off, feats, first_utt=0,
     n_utt = n_all - first_utt if n_utt is None else min(n_utt, n_all - first_utt)
     cfg = _cfg(beam, retry_beam, **kw)
     frames = C.c_int64(); utts = C.c_int32(); failed = C.c_int32(); secs = C.c_double()
-    _chk(lib().orc_em_pass_mt(C.byref(cfg), C.c_float(acoustic_scale), C.byref(m.c), _p(id2pdf, C.c_int32), id2pdf.shape[0] - 1,
-                              C.c_int32(first_utt), C.c_int32(max(n_utt, 0)), _p(fo, C.c_int64), _p(x, C.c_float),
-                              _p(g["state_off"], C.c_int64), _p(g["start"], C.c_int32), _p(g["arc_off"], C.c_int64),
-                              _p(g["ilabel"], C.c_int32), _p(g["olabel"], C.c_int32), _p(g["weight"], C.c_float),
-                              _p(g["nextstate"], C.c_int32), _p(g["final"], C.c_float), C.c_int32(num_threads),
-                              C.c_double(budget_seconds), C.byref(frames), C.byref(utts), C.byref(failed), C.byref(secs)),
-         "em_pass_mt")
+    args = (C.byref(cfg), C.c_float(acoustic_scale), C.byref(m.c), _p(id2pdf, C.c_int32), id2pdf.shape[0] - 1,
+            C.c_int32(first_utt), C.c_int32(max(n_utt, 0)), _p(fo, C.c_int64), _p(x, C.c_float),
+            _p(g["state_off"], C.c_int64), _p(g["start"], C.c_int32), _p(g["arc_off"], C.c_int64),
+            _p(g["ilabel"], C.c_int32), _p(g["olabel"], C.c_int32), _p(g["weight"], C.c_float),
+            _p(g["nextstate"], C.c_int32), _p(g["final"], C.c_float), C.c_int32(num_threads),
+            C.c_double(budget_seconds), C.byref(frames), C.byref(utts), C.byref(failed), C.byref(secs))
+    if keep is None:
+        _chk(lib().orc_em_pass_mt(*args), "em_pass_mt")
+    else:
+        n = max(n_utt, 0)
+        keep["ali"] = np.zeros(max(int(fo[first_utt + n] - fo[first_utt]), 1), np.int32)
+        keep["status"] = np.full(max(n, 1), -1, np.int32)
+        keep["like"] = np.zeros(max(n, 1), f32)
+        keep["accs"] = OAccs(int(m.gauss_off[-1]), m.miv.shape[1], id2pdf.shape[0] - 1)
+        fn = lib().orc_em_pass_mt_keep
+        fn.restype = C.c_int
+        _chk(fn(*args, _p(keep["ali"], C.c_int32), _p(keep["status"], C.c_int32), _p(keep["like"], C.c_float), C.byref(keep["accs"].c)),
+             "em_pass_mt_keep")
+        keep["status"] = keep["status"][:n]; keep["like"] = keep["like"][:n]
     return frames.value, utts.value, failed.value, secs.value
 
 

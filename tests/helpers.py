@@ -73,3 +73,49 @@ def token_path_cost(graphs, u, ali, ll_u, pdf_list, cost, id2pdf, acoustic_scale
     if not np.isfinite(fin):
         return False, np.inf
     return True, float(np.add.accumulate(terms)[-1] + np.float64(fin))
+
+
+def oracle_replay(m, gc, ut, cost, n_utt, acoustic_scale=0.1, beam=200.0, retry_beam=0.0, threads=None):
+    """The oracle's own answer for the first `n_utt` utterances of a set, computed utterance-parallel inside the C oracle
+    (orc_em_pass_mt_keep: orc_align_utterance + orc_acc_stats_ali per utterance, the calls the one-thread path makes): alignments,
+    status, like and the accumulators of those utterances.  ~30 k frames/s per core at 5000 x 64 x 40."""
+    import os
+
+    om = orc.OModel(m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    g = dict(ut.graphs)
+    g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[np.maximum(g["ilabel"], 0)], g["weight"]).astype(np.float32)
+    keep = {}
+    nthr = threads or max(1, min(len(os.sched_getaffinity(0)), 16))
+    fr, nn, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, first_utt=0, n_utt=n_utt, num_threads=nthr,
+                                       acoustic_scale=acoustic_scale, beam=beam, retry_beam=retry_beam, keep=keep)
+    assert nn == n_utt
+    keep["n_utt"], keep["frames"] = n_utt, int(ut.frame_off[n_utt])
+    return keep
+
+
+def assert_matches_oracle_replay(ctx, dm, tm, ut, res, keep, dim):
+    """K2's result `res` (ali / status / like of the whole set) against the oracle's on the replayed utterances: identical alignments,
+    same status bits, like to 2e-5; then K3 over exactly those utterances (from the oracle's alignment) against the oracle's
+    accumulators at the tolerances of tests/test_gpu_parity.py."""
+    import pytest
+
+    from kaldi_hmm_gmm_amd import DeviceAccs, UtteranceSet
+
+    n, nfr = keep["n_utt"], keep["frames"]
+    assert ((res["status"][:n] & 3) == (keep["status"] & 3)).all()
+    ok = (keep["status"] & 1) == 0
+    bad = [u for u in range(n) if not np.array_equal(res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]], keep["ali"][ut.frame_off[u]: ut.frame_off[u + 1]])]
+    assert not bad, f"{len(bad)} of {n} utterances align differently from the oracle (first: {bad[:5]})"
+    assert res["like"][:n][ok] == pytest.approx(keep["like"][ok], rel=2e-5)
+    sub = UtteranceSet(ctx, None, ut.frame_off[: n + 1].astype(np.int64), np.ascontiguousarray(ut.feats[:nfr]))
+    sub.upload_ali(np.ascontiguousarray(keep["ali"][:nfr], np.int32))
+    accs = DeviceAccs(ctx, dm, tm)
+    sub.acc_stats(dm, tm, accs)
+    got = accs.download()
+    oa = keep["accs"]
+    assert np.array_equal(got["trans_acc"], oa.trans_acc) and got["total_frames"] == oa.total_frames
+    np.testing.assert_allclose(got["occ"], oa.occ, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.mean_acc).max())
+    np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
+    assert got["total_log_like"] == pytest.approx(oa.total_log_like, rel=1e-5)
+    sub.close(); accs.close()

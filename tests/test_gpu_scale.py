@@ -1,5 +1,6 @@
-"""Size-independent properties of one EM pass at the benchmark's model shape (5000 pdfs x 64 Gaussians x 40 dims,
-bench-like utterances of 10..40 phones), far beyond what the oracle can replay in test time:
+"""One EM pass at the benchmark's model shape (5000 pdfs x 64 Gaussians x 40 dims, bench-like utterances of 10..40 phones).
+The oracle replays the first 240 utterances (~72 k frames: a few seconds on the host's cores, orc_em_pass_mt_keep) and K2 / K3 must
+give its alignments / statistics on them; the whole set of 1500 goes through size-independent properties:
 
   K1  the pdf-major and the utterance-major kernels (two independent tilings) agree within 2 float ulps on every cell
   K2  every alignment is an accepting path of its graph; the returned likelihood is that path's cost replayed on
@@ -90,6 +91,11 @@ def test_em_pass_properties_at_bench_shape(ctx, opt):
         if not np.isfinite(fin):
             return False, np.inf
         return True, float(np.add.accumulate(terms)[-1] + np.float64(fin))    # sequential (prev + w) + ac
+
+    # the oracle's FasterDecoder + acc-stats on the first 240 utterances of this very set: identical alignments, statistics to 2e-5
+    from helpers import assert_matches_oracle_replay, oracle_replay
+    keep = oracle_replay(m, gc, ut, cost, 240, acoustic_scale=0.1, beam=200.0)
+    assert_matches_oracle_replay(ctx, dm, tm, ut, res, keep, D)
 
     rng = np.random.default_rng(0)
     for u in rng.choice(U, size=120, replace=False):

@@ -1,6 +1,6 @@
 """BASELINE.json configs[4] at its REAL model shape -- 10 000 pdfs x 128 Gaussians x 80 dims (1.28 M Gaussians, 824 MB tile
-image, 1.65 GB fp64 accumulator block) -- on ~1000 bench-like utterances, through size-independent properties (the oracle
-cannot replay this in test time), plus the "fp32 stats vs fp64" accumulator tolerance report that config names:
+image, 1.65 GB fp64 accumulator block) -- on ~1000 bench-like utterances: the oracle replays the first 60 of them (identical
+alignments, statistics to 2e-5), the whole set goes through size-independent properties, plus the "fp32 stats vs fp64" accumulator tolerance report that config names:
 
   K1  pdf-major form with 8 register-resident row blocks (D > 40: KQ = 20) vs the utterance-major form: <= 2 float ulps
   K2  accepting path, returned likelihood == host replay in the token arithmetic, never worse than the generating path
@@ -84,6 +84,13 @@ def test_config5_em_pass_properties(ctx, stress, opt):
         assert -c / 0.1 == pytest.approx(float(res["like"][u]), rel=2e-6)
         ok_ref, c_ref = token_path_cost(ut.graphs, u, ut.ref_ali[sl], ll_b[u], pl, cost, m.id2pdf, 0.1)
         assert ok_ref and c <= c_ref + 1e-9
+
+    # the oracle's FasterDecoder + acc-stats on the first 60 utterances of this set (4 threads: every thread owns a 1.65 GB
+    # accumulator set at this shape): identical alignments, K3's statistics of those utterances to 2e-5
+    from helpers import assert_matches_oracle_replay, oracle_replay
+    keep = oracle_replay(m, gc, ut, cost, 60, acoustic_scale=0.1, beam=200.0, threads=4)
+    assert_matches_oracle_replay(ctx, dm, tm, ut, res, keep, D)
+    del keep
 
     # ---- K3 (block form: 128 Gaussians per pdf, D = 80) ----
     accs = DeviceAccs(ctx, dm, tm)

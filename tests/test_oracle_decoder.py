@@ -136,3 +136,35 @@ def test_gmm_decodable_path_matches_matrix_path():
         b = orc.align_utterance_ll(g, m.id2pdf, f.shape[0], pdfs, ll, acoustic_scale=0.1)
         assert a["status"] == b["status"] == 0 and (a["ali"] == b["ali"]).all() and a["like"] == b["like"]
         assert a["loglike_evals"] <= f.shape[0] * 12
+
+
+def test_threaded_pass_keeps_what_the_one_thread_path_computes():
+    """orc_em_pass_mt_keep (the utterance-parallel driver bench.py times, keeping its results for the parity check at scale): same
+    alignments, status and like as orc_align_utterance per utterance, and accumulators that sum to the one-thread accumulator."""
+    import numpy as np
+
+    from helpers import build, utt_feats
+    from oracle import oracle as orc
+
+    m, gc, om, ut, cost = build(30, 8, 20, n_utt=12, seed=5)
+    g = dict(ut.graphs)
+    g["weight"] = np.where(g["ilabel"] >= 1, g["weight"] + cost[g["ilabel"]], g["weight"]).astype(np.float32)
+    keep = {}
+    fr, nn, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, first_utt=2, n_utt=9, num_threads=3, acoustic_scale=0.1,
+                                       keep=keep)
+    assert nn == 9 and failed == 0 and fr == ut.frame_off[11] - ut.frame_off[2] and (keep["status"] == 0).all()
+    oa = orc.OAccs(int(m.gauss_off[-1]), m.dim, m.num_tids)
+    for u in range(2, 11):
+        r = orc.align_utterance(orc.OGraph.from_set(g, u), om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1)
+        a = keep["ali"][ut.frame_off[u] - ut.frame_off[2]: ut.frame_off[u + 1] - ut.frame_off[2]]
+        assert (a == r["ali"]).all() and keep["like"][u - 2] == np.float32(r["like"])
+        orc.acc_stats_ali(om, m.id2pdf, utt_feats(ut, u), r["ali"], oa)
+    np.testing.assert_allclose(keep["accs"].occ, oa.occ, rtol=1e-12)
+    np.testing.assert_allclose(keep["accs"].mean_acc, oa.mean_acc, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(keep["accs"].var_acc, oa.var_acc, rtol=1e-10, atol=1e-12)
+    assert (keep["accs"].trans_acc == oa.trans_acc).all() and keep["accs"].total_frames == oa.total_frames
+    # a budget of zero seconds reaches nothing: status stays -1
+    keep = {}
+    fr, nn, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, first_utt=0, n_utt=12, num_threads=2, budget_seconds=0.0,
+                                       acoustic_scale=0.1, keep=keep)
+    assert nn == 0 and (keep["status"] == -1).all() and keep["accs"].occ.sum() == 0
