@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--batches", type=int, default=1, help="utterance batches per rank (more batches bound the score/back-pointer buffers and let a batch's serial fallback decoder overlap the next batch's K1)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     ap.add_argument("--full-loglikes", action="store_true", help="K1 over every (frame, pdf) cell instead of only those a decoder token can read")
+    ap.add_argument("--no-band", action="store_true", help="K1 from every pdf's first readable tile to the utterance's end (khg_loglikes_reachable) instead of the band "
+                    "[first readable, last useful] tile of khg_loglikes_band (the default at beam >= 100, f16x2s form)")
     ap.add_argument("--k1", choices=["auto", "f16x2s", "f16x2", "bf16x3", "pdf", "utt"], default="auto",
                     help="K1 arithmetic / tiling (khg_ctx_set_k1_form): auto = f16x2s (fp16 matrix cores at fp32 accuracy, 3 partial "
                          "products); bf16x3 = bf16 matrix cores, 6 partial products; pdf / utt = the fp32-MFMA forms")
@@ -200,21 +202,23 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s, beam=200.0, retry_be
                       f"next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
 
 
-def check_vs_oracle(ans, ut, feats, D, sets, ctx, dm, tm, args):
+def check_vs_oracle(ans, ut, feats, D, sets, ctx, model, gc, tm, args):
     """Parity at the benchmark's scale, after the timed region: the product's alignment of the utterances the CPU baseline
     just aligned (K1 + K2 once more with the results downloaded) against the oracle's, utterance by utterance, and K3 over exactly
     those utterances against the oracle's accumulators (tolerances of tests/test_gpu_parity.py: rtol 2e-5)."""
-    from kaldi_hmm_gmm_amd import DeviceAccs, UtteranceSet
+    from kaldi_hmm_gmm_amd import DeviceAccs, DeviceModel, UtteranceSet
 
     n = int(ans["n_utt"])
     if n == 0:
         return {"oracle_utts": 0}
+    # the parameters the timed steps (and the oracle) used: the bench's own model handle went through the M-step since
+    dm = DeviceModel(ctx, model.gauss_off, gc, model.means_invvars, model.inv_vars)
     nfr = int(ut.frame_off[n])
     got_ali, got_status, got_like = [], [], []
     for s_ in sets:                                   # the sets cover the shard in utterance order
         if sum(len(x) for x in got_status) >= n:
             break
-        s_.loglikes(dm, reachable_only=not args.full_loglikes)
+        s_.loglikes(dm, reachable_only=not args.full_loglikes, band=args.band_effective)
         r = s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=True)
         got_ali.append(np.asarray(r["ali"])); got_status.append(np.asarray(r["status"])); got_like.append(np.asarray(r["like"]))
     g_ali = np.concatenate(got_ali)[:nfr]; g_status = np.concatenate(got_status)[:n]; g_like = np.concatenate(got_like)[:n]
@@ -231,7 +235,7 @@ def check_vs_oracle(ans, ut, feats, D, sets, ctx, dm, tm, args):
     acc2 = DeviceAccs(ctx, dm, tm)
     sub.acc_stats(dm, tm, acc2)
     got = acc2.download()
-    sub.close(); acc2.close()
+    sub.close(); acc2.close(); dm.close()
 
     def rel(a, b, atol):
         return float(np.max(np.abs(a - b) / (np.abs(b) + atol)))
@@ -383,7 +387,19 @@ def main():
                 skipped_cells += float(np.minimum(32 * (np.minimum(first // 16, 127) // 2), Tu).sum())
             else:
                 skipped_cells += float(np.minimum(16 * (first // 16), Tu).sum())
+    band = (not args.full_loglikes) and (not args.no_band) and k1_form == "f16x2s" and args.beam >= 100.0
+    if band:                                        # + whole 32-frame tiles past the last useful frame of a pdf
+        for s_ in sets:
+            poff_, _ = s_.pdf_lists()
+            last = s_.pdf_last_frames().astype(np.int64)
+            first = s_.pdf_first_frames().astype(np.int64)
+            Tu = np.repeat(np.diff(s_.frame_off), np.diff(poff_))
+            lt = np.minimum(np.maximum(last, 0) // 32, 254)
+            ft = np.minimum(first // 32, 255)
+            end = np.minimum(32 * (np.maximum(lt, ft - 1) + 1), Tu)      # cells up to here are computed (or skipped at the front)
+            skipped_cells += float((Tu - end).sum())
     k1_exec_frac = 1.0 - skipped_cells / max(float((T * npdf).sum()), 1.0)
+    args.band_effective = band
     kernel_ms = {}
     ev_a = torch.cuda.Event()
     ev_b = torch.cuda.Event()
@@ -406,7 +422,7 @@ def main():
         piped = dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1
         for s_ in sets:                               # batches alternate between the two streams
             if dbg: tt.append(time.perf_counter())
-            s_.loglikes(dm, reachable_only=not args.full_loglikes)
+            s_.loglikes(dm, reachable_only=not args.full_loglikes, band=band)
             if dbg: tt.append(time.perf_counter()); gm[2].record(streams[0])
             s_.align(tm, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1, download=False)
             if dbg: tt.append(time.perf_counter()); gm[3].record(streams[0])
@@ -606,6 +622,8 @@ def main():
                                                     "peak the fp32 kernels are bound by: > 1 means past that roofline"},
                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                         "executed_cell_fraction": k1_exec_frac,
+                        "k1_cells": "band: per pdf from its first readable to its last useful 32-frame tile (khg_loglikes_band)" if band else
+                                    ("all" if args.full_loglikes else "from each pdf's first readable tile (khg_loglikes_reachable)"),
                         "note": "achieved/frac: 16-bit FLOPs of the dense T x P_u contract (%d partial products per fp32 product) / kernel time "
                                 "/ the 2.5 PFLOP/s dense fp16 = bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame "
                                 "tiles (executed_cell_fraction); frac_executed = frac x that fraction.  K1 is bound by POWER: under a bare "
@@ -682,7 +700,7 @@ def main():
             ans, out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds,
                                                     beam=args.beam, retry_beam=args.retry_beam)
             # the oracle's alignments and accumulators of that sample against the product's, at the benchmark's own shape
-            out["check"].update(check_vs_oracle(ans, ut, feats, D, sets, ctxs[0], dm, tm, args))
+            out["check"].update(check_vs_oracle(ans, ut, feats, D, sets, ctxs[0], model, gc, tm, args))
         else:
             out["cpu_baseline"] = None
         record = json.dumps(out)

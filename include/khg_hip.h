@@ -162,6 +162,18 @@ int khg_loglikes(khg_ctx *ctx, const khg_model *m, khg_utts *u);
  * contents); alignments are identical to khg_loglikes + khg_align.  Sets without graphs: same as
  * khg_loglikes. */
 int khg_loglikes_reachable(khg_ctx *ctx, const khg_model *m, khg_utts *u);
+/* The BAND form: additionally leaves out what only tokens that can no longer reach a final state read -- a (pdf, 32-frame tile)
+ * past the last frame at which an arc carrying the pdf still leads to a final state by the utterance's end (fewest emitting arcs
+ * to a final state, khg_utts_pdf_last).  Those cells are FILLED with an upper bound of the pdf's log-likelihood, so the exact DP
+ * of khg_align sees such tokens at costs no higher than the reference decoder would -- its beam certificate stays sound and the
+ * best path is untouched.  An utterance whose certificate fails is recomputed without the band by khg_align itself before the
+ * order-faithful decoder reads it (the model handle must stay alive, unchanged, until that khg_align returns): alignments are
+ * identical to khg_loglikes + khg_align at any beam.  Worth it when the beam is wide (few certificates fail): ~13 % fewer cells at
+ * the benchmark's shape.  Default K1 form only (f16x2s, pdfs of more than 16 Gaussians); anything else: khg_loglikes_reachable. */
+int khg_loglikes_band(khg_ctx *ctx, const khg_model *m, khg_utts *u);
+/* per listed pdf: the last frame at which an arc carrying it can still lead to a final state by the utterance's end (-1: never;
+ * INT32_MAX for sets without graphs) */
+int khg_utts_pdf_last(const khg_utts *u, int32_t *last_h /* [pdf_off[n_utt]] */);
 /* total floats of the resident ll buffer and per-utterance offsets [n_utt+1] */
 int khg_loglikes_layout(const khg_utts *u, int64_t *ll_off_h, int64_t *total);
 int khg_loglikes_download(khg_ctx *ctx, const khg_utts *u, float *ll_h);

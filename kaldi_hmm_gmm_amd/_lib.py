@@ -97,6 +97,8 @@ SIGNATURES = {
     "khg_utts_pdf_first": (C.c_int, [vp, c_i32p]),
     "khg_loglikes": (C.c_int, [vp, vp, vp]),
     "khg_loglikes_reachable": (C.c_int, [vp, vp, vp]),
+    "khg_loglikes_band": (C.c_int, [vp, vp, vp]),
+    "khg_utts_pdf_last": (C.c_int, [vp, c_i32p]),
     "khg_loglikes_layout": (C.c_int, [vp, c_i64p, c_i64p]),
     "khg_loglikes_download": (C.c_int, [vp, vp, c_f32p]),
     "khg_loglikes_upload": (C.c_int, [vp, vp, c_f32p]),

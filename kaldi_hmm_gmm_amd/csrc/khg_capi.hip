@@ -314,6 +314,7 @@ struct khg_model {
   char* wimgs_d = nullptr;
   int32_t wimgs_tiles = 0;
   std::vector<int32_t> wimgs_key;  // [ex[0..K) of the set, S] the image was packed with (empty: stale)
+  float* ubound_d = nullptr; int32_t ubound_tiles = 0; bool ubound_valid = false;   // BAND form of K1: per-pdf upper bound of the log-likelihood (k1s_ubound)
   std::vector<int32_t> xs_ex_seen; // element-wise minimum of the feature exponents of the sets scored so far (f16x2s)
   ImgSync wimgs_sync;
   std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
@@ -349,7 +350,7 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     // any-dimension model (D > 80): no tile images; K3 still reads -0.5 * inv_vars
     m->KS = 0;
     m->wimgb_valid = false;
-    m->wimgh_ex.clear(); m->wimgs_key.clear(); m->wmax.clear(); m->k3_xb.clear();
+    m->wimgh_ex.clear(); m->wimgs_key.clear(); m->ubound_valid = false; m->wmax.clear(); m->k3_xb.clear();
     const int64_t n = m->sumG * D;
     hipLaunchKernelGGL(k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
     hipError_t e = hipGetLastError();
@@ -370,7 +371,7 @@ static int model_pack(khg_ctx* ctx, khg_model* m) {
     for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
   DEVFREE(m->tile_pdf_d);
   m->wimgh_ex.clear();
-  m->wimgs_key.clear();
+  m->wimgs_key.clear(); m->ubound_valid = false;
   m->wmax.clear(); m->k3_xb.clear();
   int rc = dev_upload(ctx, &m->tile_pdf_d, tile_pdf);
   int32_t* tile_pdf_d = m->tile_pdf_d;
@@ -418,7 +419,7 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;
@@ -489,6 +490,10 @@ struct khg_utts {
   K1Chunk* chunks_d = nullptr; int32_t n_chunks = 0; int32_t chunk_kq = 0;
   int64_t* tile_off_d = nullptr; int32_t* tiles_d = nullptr;
   std::vector<int32_t> pdf_first;  // per (utterance, listed pdf): first frame at which any state emitting it can hold a token
+  std::vector<int32_t> pdf_last;   // ... last frame at which an arc carrying it can still lead to a final state by the utterance's end (-1: never)
+  // BAND form of the default K1 (khg_loglikes_band): what khg_align needs to recompute the utterances whose beam certificate fails
+  int ll_mode = 0;                 // how the resident scores were computed: 0 every cell, 1 from the first needed tile, 2 band
+  K1sArgs band_args; khg_model* band_model = nullptr; int band_ks = 0; size_t band_lds = 0;
   int tiles_reach = -1;            // whether the walk lists carry those first frames (reachable-only K1) or zeros
   std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
   int64_t* tile2_off_d = nullptr; int32_t* tiles2_d = nullptr; std::vector<int32_t> tiles2_pto; int tiles2_reach = -1;   // bf16x3: pair walk
@@ -627,14 +632,45 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
             }
           }
         }
+        // ... and the last: from state d a final state is no fewer than dfin[d] emitting arcs away (0-1 BFS over the reversed
+        // graph from the final states), so an arc into d consumed at frame t leaves T - 1 - t frames, enough iff t <= T - 1 - dfin[d].
+        // A token past that can never reach a final state: the BAND form of K1 does not compute what only such tokens read.
+        std::vector<int32_t> dfin((size_t)S, INT32_MAX);
+        {
+          std::vector<int64_t> roff((size_t)S + 1, 0);
+          for (int64_t a = a0; a < a1; ++a) roff[(size_t)nextstate[a] + 1]++;
+          for (int64_t s = 0; s < S; ++s) roff[(size_t)s + 1] += roff[(size_t)s];
+          std::vector<int32_t> rsrc((size_t)A), rw((size_t)A), rc_((size_t)S, 0);
+          for (int64_t s = 0; s < S; ++s)
+            for (int64_t a = arc_off[s0 + s]; a < arc_off[s0 + s + 1]; ++a) {
+              const size_t pos = (size_t)(roff[(size_t)nextstate[a]] + rc_[(size_t)nextstate[a]]++);
+              rsrc[pos] = (int32_t)s; rw[pos] = ilabel[a] >= 1 ? 1 : 0;
+            }
+          std::deque<int32_t> q;
+          for (int64_t s = 0; s < S; ++s)
+            if (final_w[s0 + s] != std::numeric_limits<float>::infinity()) { dfin[(size_t)s] = 0; q.push_back((int32_t)s); }
+          while (!q.empty()) {
+            const int d = q.front(); q.pop_front();
+            for (int64_t k = roff[(size_t)d]; k < roff[(size_t)d + 1]; ++k) {
+              const int s = rsrc[(size_t)k], wgt = rw[(size_t)k];
+              if (dfin[(size_t)d] + wgt < dfin[(size_t)s]) {
+                dfin[(size_t)s] = dfin[(size_t)d] + wgt;
+                if (wgt) q.push_back(s); else q.push_front(s);
+              }
+            }
+          }
+        }
         const size_t base = u->pdf_first.size();
         u->pdf_first.resize(base + tmp_pdfs.size(), INT32_MAX);
+        u->pdf_last.resize(base + tmp_pdfs.size(), -1);
         for (int64_t s = 0; s < S; ++s) {
           if (dmin[s] == INT32_MAX) continue;
           for (int64_t a = arc_off[s0 + s]; a < arc_off[s0 + s + 1]; ++a) {
             if (ilabel[a] < 1) continue;
             const size_t j = (size_t)(std::lower_bound(tmp_pdfs.begin(), tmp_pdfs.end(), tm->id2pdf[ilabel[a]]) - tmp_pdfs.begin());
             u->pdf_first[base + j] = std::min(u->pdf_first[base + j], dmin[s]);
+            const int df = dfin[(size_t)nextstate[a]];
+            if (df != INT32_MAX) u->pdf_last[base + j] = std::max<int32_t>(u->pdf_last[base + j], (int32_t)std::max<int64_t>(-1, T - 1 - df));
           }
         }
       }
@@ -701,7 +737,7 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   if (!u || n <= 0 || !pdfs) return khg_set_error(KHG_E_ARG, "khg_utts_set_pdf_list: bad arguments");
   if (u->has_graphs) return khg_set_error(KHG_E_ARG, "khg_utts_set_pdf_list: set has graphs; its pdf lists come from them");
   u->pdfs.clear();
-  u->pdf_first.clear();     // no graphs behind an explicit list: every frame is needed
+  u->pdf_first.clear(); u->pdf_last.clear();     // no graphs behind an explicit list: every frame is needed
   for (int i = 0; i < u->n_utt; ++i) { u->pdf_off[i + 1] = u->pdf_off[i] + n; u->pdfs.insert(u->pdfs.end(), pdfs, pdfs + n); }
   plan_ll(u);
   DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d); DEVFREE(u->wchunks_d);
@@ -1244,7 +1280,8 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
 
 // K1 on the fp16 matrix cores, one accumulator per chain, transposed decomposition (khg_k1_f16x2s.hip.inc; the default).
 // -> KHG_OK, an error, or +1: outside this form's domain (the caller tries the two-accumulator f16x2 form next).
-static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachable_only) {
+static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
+  const bool reachable_only = reach != 0;
   const int KS = m->KS, D = m->D, K = 16 * KS, NMAX = k1s_nmax(KS);
   std::vector<float> xk;
   int rc = k1_maxima(ctx, m, u, &xk);
@@ -1334,22 +1371,43 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
     if (rc) return rc;
     m->wimgs_key = key;
   }
-  // one unit per (utterance, listed pdf): first W tile, number of W tiles, first needed 32-frame tile
-  if (u->sunits_pto != m->pdf_tile_off || u->sunits_reach != (int)reachable_only) {
+  // models of small pdfs (all <= 8 / <= 16 Gaussians, D <= 40): 4 / 2 pdfs share one MFMA tile (k1s_loglikes_packed)
+  int maxG = 0;
+  for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
+  const int pack = (KS != 5 || (ctx->opt[KHG_OPT_K1_DBG] & 16)) ? 1 : maxG <= 8 ? 4 : maxG <= 16 ? 2 : 1;
+  const bool band = reach == 2 && pack == 1 && u->pdf_last.size() == u->pdfs.size();     // (the packed kernel keeps the front-only form)
+  // one unit per (utterance, listed pdf): first W tile, number of W tiles, first (and, BAND form, last) needed 32-frame tile
+  if (u->sunits_pto != m->pdf_tile_off || u->sunits_reach != (band ? 2 : (int)reachable_only)) {
     DEVFREE(u->sunits_d);
     std::vector<K1sUnit> units(u->pdfs.size());
     for (size_t k = 0; k < u->pdfs.size(); ++k) {
       const int p = u->pdfs[k];
       const int nt = m->pdf_tile_off[p + 1] - m->pdf_tile_off[p];
       if (nt > 0xffff) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: a pdf of more than 2M Gaussians");
-      const int need = reachable_only ? (int)std::min<int64_t>(255, (int64_t)u->pdf_first[k] / 32) : 0;
-      units[k] = K1sUnit{m->pdf_tile_off[p], nt | (need << 16)};
+      const uint32_t need = reachable_only ? (uint32_t)std::min<int64_t>(255, (int64_t)u->pdf_first[k] / 32) : 0u;
+      // last needed tile: 255 = no limit (also a pdf no accepting path reads, last = -1: tile 0 ... nothing past it is computed
+      // only when last >= 0; a never-needed pdf keeps last tile 0 so that the kernel's [first, last] range is at most one tile)
+      uint32_t last = 255u;
+      if (band) { const int32_t pl = u->pdf_last[k]; last = pl < 0 ? 0u : (uint32_t)std::min<int32_t>(255, pl / 32); }
+      units[k] = K1sUnit{m->pdf_tile_off[p], (uint32_t)nt | (need << 16) | (last << 24)};
     }
     rc = dev_upload(ctx, &u->sunits_d, units);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     u->sunits_pto = m->pdf_tile_off;
-    u->sunits_reach = (int)reachable_only;
+    u->sunits_reach = band ? 2 : (int)reachable_only;
+  }
+  // BAND form: the per-pdf upper bounds the skipped tiles are filled with, indexed by a pdf's first W tile; per parameter version
+  if (band && !m->ubound_valid) {
+    if (!m->ubound_d || m->ubound_tiles < m->ntiles) {
+      DEVFREE(m->ubound_d);
+      rc = dev_alloc(&m->ubound_d, (size_t)m->ntiles);
+      if (rc) return rc;
+      m->ubound_tiles = m->ntiles;
+    }
+    hipLaunchKernelGGL(k1s_ubound, dim3(m->P), dim3(64), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, D, m->ubound_d);
+    HIPCHK(hipGetLastError());
+    m->ubound_valid = true;
   }
   K1sArgs a;
   a.xs = u->xs_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->schunks_d;
@@ -1358,14 +1416,13 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
   a.c1 = std::ldexp(1.44269504088896340736f, -S);
   a.inv_scale = std::ldexp(1.0f, -S);
   a.mfloor = -3.0e38f / std::max(1.0f, a.c1);
+  a.ubound = band ? m->ubound_d : nullptr; a.repair_status = nullptr; a.repair_bit = 0;
+  u->ll_mode = band ? 2 : (reachable_only ? 1 : 0);
   if (u->n_schunks > 0) {
     rc = m->wimgs_sync.before_read(ctx->stream);
     if (rc) return rc;
     const size_t lds = (size_t)NMAX * k1s_xtile_bytes(KS) + 64;     // + the work-item counter
-    // models of small pdfs (all <= 8 / <= 16 Gaussians, D <= 40): 4 / 2 pdfs share one MFMA tile (k1s_loglikes_packed)
-    int maxG = 0;
-    for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
-    const int pack = (KS != 5 || (ctx->opt[KHG_OPT_K1_DBG] & 16)) ? 1 : maxG <= 8 ? 4 : maxG <= 16 ? 2 : 1;
+    if (band) { u->band_args = a; u->band_model = m; u->band_ks = KS; u->band_lds = lds; }
     const void* fn = pack == 4 ? (const void*)k1s_loglikes_packed<5, 4> : pack == 2 ? (const void*)k1s_loglikes_packed<5, 2>
                      : KS == 5 ? (const void*)k1s_loglikes<5> : (const void*)k1s_loglikes<10>;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1384,9 +1441,11 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachab
   return KHG_OK;
 }
 
-static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
+static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reach) {
   if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
-  if (u->pdf_first.size() != u->pdfs.size()) reachable_only = false;
+  if (u->pdf_first.size() != u->pdfs.size()) reach = 0;
+  const bool reachable_only = reach != 0;
+  u->ll_mode = reachable_only ? 1 : 0;
   if (m->D != u->D) return khg_set_error(KHG_E_RUNTIME, "Dim mismatch: data dim = " + std::to_string(u->D) + " vs. model dim = " + std::to_string(m->D));
   if (u->pdfs_checked_P != m->P) {     // once per (set, model size): 7 M entries at the bench size, 1.5 ms of host time per call
     for (int32_t p : u->pdfs)
@@ -1410,7 +1469,7 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool rea
     if (u->N == 0 || u->pdfs.empty()) { u->ll_valid = true; return KHG_OK; }
     if (m->KQ == 0) return loglikes_wide(ctx, m, u);      // D > 80: one form
     if (form == KHG_K1_F16X2S) {
-      rc = loglikes_f16x2s(ctx, const_cast<khg_model*>(m), u, reachable_only);
+      rc = loglikes_f16x2s(ctx, const_cast<khg_model*>(m), u, reach);
       if (rc <= 0) return rc;
       form = KHG_K1_F16X2;           // the absolute part of its error bound is too large for this model: two accumulators
     }
@@ -1478,8 +1537,15 @@ extern "C" int khg_utts_pdf_first(const khg_utts* u, int32_t* first) {
   else std::copy(u->pdf_first.begin(), u->pdf_first.end(), first);
   return KHG_OK;
 }
-extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, false); }
-extern "C" int khg_loglikes_reachable(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, true); }
+extern "C" int khg_loglikes(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, 0); }
+extern "C" int khg_loglikes_reachable(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, 1); }
+extern "C" int khg_loglikes_band(khg_ctx* ctx, const khg_model* m, khg_utts* u) { return loglikes_impl(ctx, m, u, 2); }
+extern "C" int khg_utts_pdf_last(const khg_utts* u, int32_t* last) {
+  if (!u || !last) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (u->pdf_last.size() != u->pdfs.size()) std::fill(last, last + u->pdfs.size(), INT32_MAX);
+  else std::copy(u->pdf_last.begin(), u->pdf_last.end(), last);
+  return KHG_OK;
+}
 extern "C" int khg_loglikes_layout(const khg_utts* u, int64_t* ll_off, int64_t* total) {
   if (!u) return khg_set_error(KHG_E_ARG, "bad arguments");
   if (ll_off) std::copy(u->ll_off.begin(), u->ll_off.end(), ll_off);
@@ -1508,6 +1574,7 @@ extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
   }
   HIPCHK(hipMemcpyAsync(u->ll_d, ll, sizeof(float) * (size_t)u->ll_total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  u->ll_mode = 0; u->band_model = nullptr;      // the caller's scores: every cell as given
   u->ll_valid = true;
   return KHG_OK;
 }
@@ -1649,6 +1716,24 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   hipStream_t side = ctx->sides[ctx->next_side];
   ctx->next_side = (ctx->next_side + 1) % khg_ctx::NSIDE;
   HIPCHK(hipStreamWaitEvent(side, u->ev_dp, 0));
+  if (u->ll_mode == 2 && u->band_model && u->n_schunks > 0) {
+    // BAND form of K1: the utterances the DP could not certify are about to be decoded by the order-faithful kernel, which reads
+    // every cell a token reaches -- also the ones the band left at their upper bound.  Recompute exactly those utterances (from
+    // their first needed tile on, no upper limit); a workgroup of any other utterance returns at once.
+    K1sArgs ra = u->band_args;
+    ra.repair_status = u->status_d; ra.repair_bit = K2_ST_NEED_FALLBACK;
+    khg_model* bm = u->band_model;
+    rc = bm->wimgs_sync.before_read(side);
+    if (rc) return rc;
+    {
+      KernelTimer kt(ctx, "k1_band_repair", side);
+      if (u->band_ks == 5) hipLaunchKernelGGL((k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), u->band_lds, side, ra);
+      else hipLaunchKernelGGL((k1s_loglikes<10>), dim3(u->n_schunks), dim3(512), u->band_lds, side, ra);
+    }
+    HIPCHK(hipGetLastError());
+    rc = bm->wimgs_sync.after_read(side);
+    if (rc) return rc;
+  }
   {
     KernelTimer kt(ctx, "k2_viterbi_faithful", side);
     // wave-parallel form for graphs of <= 1000 states (any out-degree, epsilon-input arcs handled by a lane-0 worklist over

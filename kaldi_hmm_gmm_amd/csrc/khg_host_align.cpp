@@ -67,7 +67,10 @@ std::vector<AlignResult> AlignBatch(const AmDiagGmm& am, const TransitionModel& 
     if (nframes[(size_t)u] > 0) std::memcpy(all.data() + (size_t)frame_off[(size_t)u] * D, feats[(size_t)u], sizeof(float) * (size_t)nframes[(size_t)u] * D);
   CApi(khg_utts_create(ctx, dt.h, n_utt, D, frame_off.data(), all.data(), nullptr, g.state_off.data(), g.start.data(), g.arc_off.data(), g.ilabel.data(),
                        g.olabel.data(), g.weight.data(), g.nextstate.data(), g.final_w.data(), &us.h));
-  CApi(khg_loglikes_reachable(ctx, dm.h, us.h));      // only the cells a decoder token can read
+  // only the cells a decoder token can read; with a wide beam (few failed beam certificates to repair) also not the cells that only
+  // tokens past any accepting path read (khg_loglikes_band: identical alignments, ~13 % fewer cells on chain graphs)
+  if (config.beam >= 100.0f) CApi(khg_loglikes_band(ctx, dm.h, us.h));
+  else CApi(khg_loglikes_reachable(ctx, dm.h, us.h));
   khg_align_config c;
   khg_align_config_default(&c);
   c.beam = config.beam; c.retry_beam = config.retry_beam; c.careful = config.careful ? 1 : 0; c.acoustic_scale = acoustic_scale;

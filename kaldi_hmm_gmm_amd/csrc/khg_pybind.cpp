@@ -365,7 +365,7 @@ py::dict KModel::mle_update_finish() {
 
 struct KUtts {
   khg_utts* h = nullptr;
-  py::object ctx_obj, keep;
+  py::object ctx_obj, keep, keep_model;
   KContext* ctx;
   Arr<int64_t> frame_off;
   int n_utt = 0, dim = 0;
@@ -421,7 +421,20 @@ struct KUtts {
     Check(khg_utts_pdf_first(h, first.mutable_data()));
     return py::array(first)[py::slice(0, n, 1)];
   }
-  void loglikes(KModel& m, bool reachable_only) { Check(NoGil([&] { return reachable_only ? khg_loglikes_reachable(ctx->h, m.h, h) : khg_loglikes(ctx->h, m.h, h); })); }
+  py::object pdf_last_frames() {
+    Arr<int64_t> off({(py::ssize_t)n_utt + 1});
+    Check(khg_utts_num_pdfs(h, off.mutable_data()));
+    const py::ssize_t n = off.at(n_utt);
+    Arr<int32_t> last({n > 0 ? n : 1});
+    Check(khg_utts_pdf_last(h, last.mutable_data()));
+    return py::array(last)[py::slice(0, n, 1)];
+  }
+  // reachable_only: from each pdf's first readable frame (khg_loglikes_reachable); band: ... up to its last useful frame, the rest
+  // filled with an upper bound (khg_loglikes_band; `model` must stay alive until the align that follows has returned)
+  void loglikes(KModel& m, bool reachable_only, bool band) {
+    keep_model = band ? py::cast(&m) : py::object();
+    Check(NoGil([&] { return band ? khg_loglikes_band(ctx->h, m.h, h) : reachable_only ? khg_loglikes_reachable(ctx->h, m.h, h) : khg_loglikes(ctx->h, m.h, h); }));
+  }
   py::tuple loglikes_layout() {
     Arr<int64_t> off({(py::ssize_t)n_utt + 1});
     int64_t tot = 0;
@@ -575,7 +588,8 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def_readonly("ctx", &KUtts::ctx_obj).def_readonly("frame_off", &KUtts::frame_off).def_readonly("n_utt", &KUtts::n_utt)
       .def_readonly("dim", &KUtts::dim)
       .def("set_pdf_list", &KUtts::set_pdf_list).def("features_changed", &KUtts::features_changed).def("pdf_lists", &KUtts::pdf_lists).def("pdf_first_frames", &KUtts::pdf_first_frames)
-      .def("loglikes", &KUtts::loglikes, py::arg("model"), py::arg("reachable_only") = false)
+      .def("pdf_last_frames", &KUtts::pdf_last_frames)
+      .def("loglikes", &KUtts::loglikes, py::arg("model"), py::arg("reachable_only") = false, py::arg("band") = false)
       .def("loglikes_layout", &KUtts::loglikes_layout).def("download_loglikes", &KUtts::download_loglikes)
       .def("upload_loglikes", &KUtts::upload_loglikes)
       .def("align", &KUtts::align, py::arg("tm"), py::arg("beam") = 200.0f, py::arg("retry_beam") = 0.0f, py::arg("acoustic_scale") = 1.0f,

@@ -38,6 +38,10 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "frames/s" and cb["sample"]
     assert d["m_step"]["device"]["params_bit_equal_to_host"] is True
+    # parity at the bench's own shape, on the record: the utterances the CPU baseline aligned, against K1 + K2 + K3
+    ck = d["check"]
+    assert ck["oracle_utts"] >= 20 and ck["ali_mismatch_utts"] == 0 and ck["status_mismatch"] == 0 and ck["like_max_rel_err"] < 2e-5
+    assert ck["stats_within_2e-5"] is True and ck["trans_acc_equal"] is True and ck["total_frames_equal"] is True
 
 
 @pytest.mark.gpu

@@ -821,3 +821,90 @@ def test_features_changed_repacks_the_planes(ctx, opt):
             exact, bound = exact_loglikes(m, gc, x, pl)
             assert (np.abs(got[u] - exact) <= LL_ATOL + LL_RTOL * bound).all()
     us.close()
+
+
+def _last_frames(graphs, u, id2pdf, pdf_list, T):
+    """last frame at which an arc carrying each pdf can still lead to a final state by frame T (host restatement of pdf_last)."""
+    g = graphs
+    s0, s1 = int(g["state_off"][u]), int(g["state_off"][u + 1])
+    S = s1 - s0
+    ao = g["arc_off"]
+    dfin = np.full(S, 10**9, np.int64)
+    fin = np.isfinite(g["final"][s0:s1])
+    dfin[fin] = 0
+    changed = True
+    while changed:                      # Bellman-Ford on the reversed graph (tiny graphs): emitting arcs weigh 1, epsilons 0
+        changed = False
+        for s in range(S):
+            for a in range(int(ao[s0 + s]), int(ao[s0 + s + 1])):
+                d, w = int(g["nextstate"][a]), int(g["ilabel"][a] >= 1)
+                if dfin[d] + w < dfin[s]:
+                    dfin[s] = dfin[d] + w; changed = True
+    last = {int(p): -1 for p in pdf_list}
+    for s in range(S):
+        for a in range(int(ao[s0 + s]), int(ao[s0 + s + 1])):
+            if g["ilabel"][a] >= 1 and dfin[int(g["nextstate"][a])] < 10**9:
+                p = int(id2pdf[g["ilabel"][a]])
+                last[p] = max(last[p], T - 1 - int(dfin[int(g["nextstate"][a])]))
+    return last
+
+
+@pytest.mark.parametrize("beam,retry,max_active", [(200.0, 0.0, 2**31 - 1), (2.0, 30.0, 2**31 - 1), (200.0, 0.0, 100000)])
+def test_band_loglikes_fill_only_dead_cells_and_align_identically(ctx, opt, beam, retry, max_active):
+    """khg_loglikes_band (default K1 form): between a pdf's first and last needed 32-frame tile the scores are bit-identical to the
+    full matrix; whole tiles past the last needed one hold an UPPER BOUND of the pdf's log-likelihood (>= every true value of that
+    pdf); and khg_align gives the alignment of the full matrix -- through the exact DP + certificate, or (max_active
+    set: the DP certifies nothing, every utterance goes this way) through the repair launch + order-faithful decoder -- which is
+    the oracle's."""
+    opt.k1("f16x2s")
+    m, gc, om, ut, cost = build(150, 64, 40, n_utt=12, seed=78, min_phones=12, max_phones=40)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    full = us.download_loglikes()
+    res_full = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1, max_active=max_active)
+    poff, pdfs = us.pdf_lists()
+    last_dev = us.pdf_last_frames()
+    POISON = np.float32(12345.0)
+    us.upload_loglikes([np.full_like(f, POISON) for f in full])
+    us.loglikes(dm, band=True)
+    part = us.download_loglikes()
+    filled = total = 0
+    for u in range(us.n_utt):
+        pl = pdfs[poff[u]: poff[u + 1]]
+        T = int(ut.frame_off[u + 1] - ut.frame_off[u])
+        first = _first_frames(ut.graphs, u, m.id2pdf, pl)
+        last = _last_frames(ut.graphs, u, m.id2pdf, pl, T)
+        assert [last[int(p)] for p in pl] == last_dev[poff[u]: poff[u + 1]].tolist()
+        for j, p in enumerate(pl):
+            t0 = 32 * (min(first[int(p)], 10**6) // 32)
+            t1 = min(32 * (max(last[int(p)], 0) // 32 + 1), full[u].shape[1])
+            assert np.array_equal(part[u][j, t0:t1], full[u][j, t0:t1]), (u, j)
+            tail = part[u][j, max(t1, t0):]
+            if tail.size:
+                assert (tail == tail[0]).all() and tail[0] != POISON, "tiles past the band hold one fill value"
+                assert tail[0] >= full[u][j].max() and tail[0] >= full[u][j, max(t1, t0):].max(), "... an upper bound of the pdf's scores"
+                filled += tail.size
+            total += full[u].shape[1]
+    assert filled > 0.05 * total, (filled, total)
+    res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1, max_active=max_active)
+    assert np.array_equal(res["ali"], res_full["ali"]) and np.array_equal(res["status"] & 3, res_full["status"] & 3)
+    np.testing.assert_array_equal(res["like"], res_full["like"])
+    nfb = int(((res["status"] & 8) != 0).sum())
+    if max_active < 2**31 - 1:
+        assert nfb == us.n_utt, "max_active was meant to send every utterance through the repair launch"
+        # after the repair the flagged utterances hold real scores from their first needed tile on
+        part2 = us.download_loglikes()
+        for u in np.nonzero(res["status"] & 8)[0]:
+            pl = pdfs[poff[u]: poff[u + 1]]
+            first = _first_frames(ut.graphs, int(u), m.id2pdf, pl)
+            for j, p in enumerate(pl):
+                t0 = 32 * (min(first[int(p)], 10**6) // 32)
+                assert np.array_equal(part2[u][j, t0:], full[u][j, t0:]), (u, j)
+    for u in range(us.n_utt):
+        want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1, beam=beam, retry_beam=retry,
+                                   max_active=max_active)
+        a = res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]]
+        assert (int(res["status"][u]) & 3) == (want["status"] & 3)
+        if not want["status"] & 1:
+            assert (a == want["ali"]).all(), u
+    print(f"beam {beam}: band fill fraction {filled / total:.3f}, {nfb}/{us.n_utt} utterances repaired + decoded order-faithfully")
