@@ -72,10 +72,19 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    err = r.stderr.decode("utf-8", "replace")
     lines = [ln for ln in r.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
+    if r.returncode or not lines:
+        # what the ranks said last: torch.distributed.run names the failing rank, the ranks' own messages sit above that
+        tail = err.splitlines()[-60:]
+        print(f"bench.py: the {args.gpus}-rank launch ended with return code {r.returncode}; last lines of its stderr:", file=sys.stderr)
+        for ln in tail:
+            print("  | " + ln, file=sys.stderr)
+    else:
+        sys.stderr.write(err[-2000:])
     sys.exit(r.returncode if r.returncode else (0 if lines else 3))
 
 
@@ -200,6 +209,29 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s, beam=200.0, retry_be
                       f"{nthr} POSIX threads inside the C oracle ({ncpu} logical CPUs visible, CPU quota {quota}; gcc -O3 -march=native, "
                       f"utterance-parallel, private accumulators): "
                       f"next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
+
+
+def shard_efficiency(args, world, per_rank, kernel_ms):
+    """How close this N-rank run is to N times one GPU working on a shard of THIS size: rank 0's kernel time per step against the
+    committed N = 1 line of the same shard size (profiles/r4_shard_lines.json: bench.py --utts <utts / N>), i.e. what the exchange
+    and the imbalance between shards cost, with the small-shard effect (fewer, shorter launches per kernel) taken out."""
+    if world <= 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r4_shard_lines.json")) as fh:
+            lines = json.load(fh)
+    except Exception:
+        return {"value": None, "why": "no profiles/r4_shard_lines.json"}
+    key = f"{args.config}:{args.utts // world}"
+    ref = lines.get(key)
+    if not ref:
+        return {"value": None, "why": f"no committed N = 1 line for {key}"}
+    mine = sum(v for k, v in kernel_ms.items() if not k.startswith("c1_")) / args.steps
+    slowest = max(sum(v for k, v in r["kernel_ms_per_step"].items() if not k.startswith("c1_")) for r in per_rank)
+    return {"value": ref["ms_per_step"] / max(r["seconds"] * 1e3 / args.steps for r in per_rank),
+            "n1_shard_ms_per_step": ref["ms_per_step"], "n1_shard_kernel_ms": ref["kernel_ms"], "rank0_kernel_ms": mine, "slowest_rank_kernel_ms": slowest,
+            "note": "n1_shard_ms_per_step / this run's slowest rank's ms per step; 1.0 = the shard runs as fast as it does alone on one GPU "
+                    "(exchange fully hidden, shards balanced)"}
 
 
 def check_vs_oracle(ans, ut, feats, D, sets, ctx, model, gc, tm, args):
@@ -364,10 +396,13 @@ def main():
     comm = None
     if dist_on and args.allreduce in ("khg", "khg-f32"):
         try:
-            comm = make_comm(ctxs[0])             # None in a one-rank group
-        except Exception as ex:                   # a rank without its communicator must not leave the others in a barrier
-            print(f"bench.py: rank {rank}: the library's RCCL communicator could not be formed: {ex}", file=sys.stderr, flush=True)
-            os._exit(3)                           # the launcher (torch.distributed.run) then takes the other ranks down
+            # (a one-rank group -- KHG_BENCH_FORCE_DIST=1 -- forms a real one-rank RCCL communicator: the same entry points run)
+            comm = make_comm(ctxs[0], one_rank=True, timeout_s=float(os.environ.get("KHG_BENCH_COMM_TIMEOUT", "180")))
+        except BaseException as ex:               # a rank without its communicator must not leave the others in a barrier
+            print(f"bench.py: rank {rank}/{world} (device {local}): the library's RCCL communicator could not be formed: {ex!r}",
+                  file=sys.stderr, flush=True)
+            os._exit(3)                           # fresh-process semantics only: exit (never re-exec a process that touched the GPU);
+            #                                       the launcher (torch.distributed.run) then takes the other ranks down
     host_block = np.zeros(accs.size, np.float64) if args.allreduce == "host" else None
 
     T = np.diff(ut.frame_off)
@@ -511,6 +546,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         frames_total = int(t[1])
+    # C1 once more, un-pipelined and alone on the stream (nothing to hide behind): what the exchange itself costs at this N
+    rccl_info = None
+    if dist_on and args.allreduce in ("khg", "khg-f32"):
+        c1_alone = None
+        if comm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            scratch = DeviceAccs(ctxs[0], dm, tm)     # a block of the same size (zeros): the real one keeps this step's sums
+            torch.cuda.synchronize()
+            e0.record(streams[0])
+            scratch.allreduce(comm)
+            e1.record(streams[0])
+            torch.cuda.synchronize()
+            c1_alone = e0.elapsed_time(e1)
+            scratch.close()
+        info = comm.info() if comm is not None else {"nranks": 0, "rank": -1, "version": 0}
+        v = int(info["version"])
+        rccl_info = {"nranks": int(info["nranks"]), "rank": int(info["rank"]), "version_code": v,
+                     "version": "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v >= 10000 else str(v),
+                     "c1_ms_alone": c1_alone, "c1_bytes": int(accs.size) * 8,
+                     "c1_GBps_alone": (int(accs.size) * 8 / (c1_alone * 1e-3) / 1e9) if c1_alone else None,
+                     "note": "nranks / rank / version are what RCCL reports for the communicator the exchange ran on (ncclCommCount, "
+                             "ncclCommUserRank, ncclGetVersion); c1_ms_alone = one un-pipelined khg_accs_allreduce of the whole fp64 block, "
+                             "timed by HIP events after the timed steps"}
     k1_total_ms = kernel_ms.get("k1_loglikes", 0.0)
     k1_avg_ms = k1_total_ms / n_local_launches
     k1_flops_per_launch = k1_flops / nb
@@ -688,6 +748,8 @@ def main():
             "check": {"acc_total_frames": res["total_frames"], "frames_in_set": frames_global, "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
             "allreduce": args.allreduce if dist_on else None,
+            "rccl": rccl_info,
+            "scaling_efficiency_vs_n1_shard": shard_efficiency(args, world, per_rank, kernel_ms),
             "c1_pipelined_parts": args.c1_parts if (dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1) else None,
             "per_rank": per_rank if world > 1 else None,
         }

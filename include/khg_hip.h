@@ -291,6 +291,9 @@ int khg_accs_allreduce_f32(khg_ctx *ctx, khg_accs *a, void *comm);
 int khg_comm_unique_id(void *id_out /* [KHG_COMM_ID_BYTES] */);
 int khg_comm_create(khg_ctx *ctx, int32_t nranks, int32_t rank, const void *id, void **comm_out);
 int khg_comm_destroy(void *comm);
+/* what RCCL reports for a communicator (any of the outputs may be NULL): ncclCommCount, ncclCommUserRank, ncclGetVersion
+ * (comm == NULL: only the version) -- lets a multi-GPU run state on its own record how many ranks the collective really spanned */
+int khg_comm_info(void *comm, int32_t *nranks, int32_t *rank, int32_t *version);
 
 /* ---- host-side M-step and helpers (no GPU needed) --------------------------------------- */
 /* DiagGmm::ComputeGconsts (csrc/diag-gmm.cc:103-147) for a ragged model; num_bad_out may be NULL */

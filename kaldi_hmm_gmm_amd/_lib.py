@@ -104,6 +104,7 @@ SIGNATURES = {
     "khg_loglikes_upload": (C.c_int, [vp, vp, c_f32p]),
     "khg_utts_set_pdf_list": (C.c_int, [vp, C.c_int32, c_i32p]),
     "khg_utts_features_changed": (C.c_int, [vp]),
+    "khg_comm_info": (C.c_int, [vp, c_i32p, c_i32p, c_i32p]),
     "khg_align_config_default": (None, [C.POINTER(AlignConfigC)]),
     "khg_align": (C.c_int, [vp, vp, vp, C.POINTER(AlignConfigC), c_i32p, c_i32p, c_i64p, C.c_int64, c_f32p, c_i32p]),
     "khg_ali_upload": (C.c_int, [vp, vp, c_i32p]),

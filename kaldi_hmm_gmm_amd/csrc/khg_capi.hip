@@ -2184,6 +2184,9 @@ struct RcclApi {
   int (*GroupStart)() = nullptr;
   int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;      // optional (sharded M-step)
   int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;            // optional (khg_comm_info)
+  int (*CommUserRank)(void*, int*) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -2206,6 +2209,9 @@ static int rccl_bind() {
   a.Reduce = reinterpret_cast<decltype(a.Reduce)>(dlsym(h, "ncclReduce"));
   a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(h, "ncclBroadcast"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
+  a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+  a.GetVersion = reinterpret_cast<decltype(a.GetVersion)>(dlsym(h, "ncclGetVersion"));
   if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString || !a.GroupStart || !a.GroupEnd)
     return khg_set_error(KHG_E_UNSUPPORTED, "RCCL library lacks ncclAllReduce / ncclCommInitRank");
   g_rccl = a;
@@ -2295,6 +2301,16 @@ extern "C" int khg_comm_create(khg_ctx* ctx, int32_t nranks, int32_t rank, const
   int r = g_rccl.CommInitRank(&comm, nranks, uid, rank);
   if (r) return rccl_fail("ncclCommInitRank", r);
   *comm_out = comm;
+  return KHG_OK;
+}
+// what RCCL itself says about a communicator: the number of ranks it spans, this process's rank in it, the library's version code
+extern "C" int khg_comm_info(void* comm, int32_t* nranks, int32_t* rank, int32_t* version) {
+  int rc = rccl_bind();
+  if (rc) return rc;
+  int v = 0;
+  if (nranks) { *nranks = 0; if (comm && g_rccl.CommCount) { int r = g_rccl.CommCount(comm, &v); if (r) return rccl_fail("ncclCommCount", r); *nranks = v; } }
+  if (rank) { *rank = -1; if (comm && g_rccl.CommUserRank) { int r = g_rccl.CommUserRank(comm, &v); if (r) return rccl_fail("ncclCommUserRank", r); *rank = v; } }
+  if (version) { *version = 0; if (g_rccl.GetVersion) { int r = g_rccl.GetVersion(&v); if (r) return rccl_fail("ncclGetVersion", r); *version = v; } }
   return KHG_OK;
 }
 extern "C" int khg_comm_destroy(void* comm) {

@@ -118,7 +118,14 @@ struct KComm {
   KComm(KContext& ctx, int n, int r, py::bytes uid) : nranks(n), rank(r) {
     std::string s = uid;
     if (s.size() != KHG_COMM_ID_BYTES) throw py::value_error("Comm: the id is 128 bytes");
-    Check(khg_comm_create(ctx.h, n, r, s.data(), &h));
+    Check(NoGil([&] { return khg_comm_create(ctx.h, n, r, s.data(), &h); }));      // collective: blocks until every rank has called it
+  }
+  py::dict info() {          // what RCCL itself reports: ncclCommCount / ncclCommUserRank / ncclGetVersion
+    int32_t n = 0, r = -1, v = 0;
+    Check(khg_comm_info(h, &n, &r, &v));
+    py::dict d;
+    d["nranks"] = n; d["rank"] = r; d["version"] = v;
+    return d;
   }
   ~KComm() { close(); }
   void close() { if (h) { khg_comm_destroy(h); h = nullptr; } }
@@ -540,7 +547,7 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def_static("unique_id", &KComm::unique_id)
       .def(py::init<KContext&, int, int, py::bytes>(), py::arg("ctx"), py::arg("nranks"), py::arg("rank"), py::arg("uid"), py::keep_alive<1, 2>())
       .def_property_readonly("h", [](KComm& c) { return reinterpret_cast<uintptr_t>(c.h); })
-      .def_readonly("nranks", &KComm::nranks).def_readonly("rank", &KComm::rank).def("close", &KComm::close)
+      .def_readonly("nranks", &KComm::nranks).def_readonly("rank", &KComm::rank).def("close", &KComm::close).def("info", &KComm::info)
       .def_property_readonly_static("ID_BYTES", [](py::object) { return KHG_COMM_ID_BYTES; });
 
   py::class_<KModel>(m, "DeviceModel")

@@ -59,18 +59,42 @@ def take_utterances(frame_off, graphs: Dict[str, np.ndarray], idx) -> Tuple[np.n
     return fo, g, frames
 
 
-def make_comm(ctx):
+def make_comm(ctx, one_rank=False, timeout_s=None):
     """The library's RCCL communicator over the ranks of the initialised torch.distributed group (any backend:
-    the group only carries the 128-byte id from rank 0).  None for a one-rank job."""
+    the group only carries the 128-byte id from rank 0).  None for a one-rank job, unless ``one_rank`` asks for a
+    one-rank communicator (the collective code path on a one-GPU box).  ``timeout_s``: communicator formation is a collective
+    that blocks while a rank is missing; past the timeout a TimeoutError is raised in THIS process (the caller decides how to
+    leave: a process that has touched the GPU must exit, not re-exec)."""
     import torch.distributed as dist
 
     from .device import Comm
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    up = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if up else 1
+    if world == 1 and not one_rank:
         return None
-    box = [Comm.unique_id() if dist.get_rank() == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    return Comm(ctx, dist.get_world_size(), dist.get_rank(), box[0])
+    rank = dist.get_rank() if up else 0
+    box = [Comm.unique_id() if rank == 0 else None]
+    if up and world > 1:
+        dist.broadcast_object_list(box, src=0)
+    if timeout_s is None:
+        return Comm(ctx, world, rank, box[0])
+    import threading
+    out = {}
+
+    def form():
+        try:
+            out["comm"] = Comm(ctx, world, rank, box[0])      # releases the GIL while ncclCommInitRank blocks
+        except BaseException as ex:                           # noqa: B036  (handed to the caller's thread)
+            out["error"] = ex
+    th = threading.Thread(target=form, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        raise TimeoutError(f"rank {rank}: ncclCommInitRank over {world} ranks did not return within {timeout_s:g} s")
+    if "error" in out:
+        raise out["error"]
+    return out["comm"]
 
 
 def allreduce_accs(acc_tensor):

@@ -58,3 +58,7 @@ def test_bench_collective_path_in_a_one_rank_group():
     assert d["n_gpus"] == 1 and d["value"] > 1e6 and d["cpu_baseline"] is None
     assert d["check"]["acc_total_frames"] == d["config"]["frames_per_step"]      # the all-reduce of one rank is the identity
     assert d["allreduce_ms_per_step"] is not None and d["allreduce_ms_per_step"] >= 0.0 and d["allreduce_bytes"] > 0
+    # the run says itself how many ranks RCCL saw and what the exchange costs alone (a one-rank RCCL communicator here)
+    rc = d["rccl"]
+    assert rc["nranks"] == 1 and rc["rank"] == 0 and rc["version_code"] > 20000 and rc["c1_ms_alone"] >= 0.0 and rc["c1_bytes"] == d["allreduce_bytes"]
+    assert d["scaling_efficiency_vs_n1_shard"] is None          # only reported for N > 1
