@@ -153,7 +153,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 1}, {0, 64}, {0, 1}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
@@ -177,10 +177,11 @@ static void ctx_defaults_from_env(khg_ctx* c) {
     {"KHG_K1B_DBG", KHG_OPT_K1_DBG, ""}, {"KHG_K2_INORDER", KHG_OPT_K2_INORDER, ""}, {"KHG_K2_KS", KHG_OPT_K2_KS, ""},
     {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},
     {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1,count=2"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
-    {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1"},
+    {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1,f16=2"},
     {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}, {"KHG_K3_PHASEA", KHG_OPT_K3_PHASE_A, "auto=0,f16=0,f32=1"}};
   c->opt[KHG_OPT_K1_INTERLEAVE] = -1;
   c->opt[KHG_OPT_K1P_TS] = 1024;
+  c->opt[KHG_OPT_K3_PHASE_B] = 2;        // both phases of K3's wave form on the fp16 matrix cores where they apply (else the fp64 pipe)
   for (const auto& t : tab) {
     const char* e = getenv(t.name);
     if (!e || !*e) continue;
@@ -2041,11 +2042,15 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       bool f16a = false;
       // (pdfs of <= 32 Gaussians keep the fp32 chain: 40 MFMAs per tile are not worth the split, and the two-waves-per-SIMD
       //  instantiations have no registers for the fp16 W pieces)
-      if (nb >= 3 && ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] == 0) { rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &f16a); if (rc) return rc; }
+      if (nb >= 3 && ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] != 1) { rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &f16a); if (rc) return rc; }
       if (f16a) {
         a.pa_ex = m->k3_ex_d; a.pa_S = m->k3_S;
         a.pa_scale = std::ldexp(1.0f, m->k3_S); a.pa_inv = std::ldexp(1.0f, -m->k3_S); a.pa_c1 = std::ldexp(1.44269504088896340736f, -m->k3_S);
       }
+      // phase B on the fp16 matrix cores as well (k3_accumulate_wave16; KHG_OPT_K3_PHASE_B = 2): where phase A's split planes exist
+      // and the weight is an ordinary number
+      const bool f16b = f16a && ctx->opt[KHG_OPT_K3_PHASE_B] == 2 && std::isfinite(weight) && std::fabs(weight) > 1.0e-30f && std::fabs(weight) < 1.0e30f;
+      if (f16b) { a.pb_SG = 13 - std::ilogb(std::fabs(weight)); a.pb_gscale = std::ldexp(1.0f, a.pb_SG); }
       // fp32 phase A: W + the waves' planes; fp16 phase A: the waves' planes + their split planes; then the fold image
       const size_t lds = std::max<size_t>(f16a ? sizeof(float) * (4 * 4 * 16 * 20) + 2 * (size_t)(4 * 2 * 16 * K3_XH_ROW)
                                                : sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 4 * 16 * 20),
@@ -2077,14 +2082,20 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       KernelTimer kt(ctx, "k3_accumulate");
       // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
       // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
-      const bool exact_b = ctx->opt[KHG_OPT_K3_PHASE_B] == 0;
+      const bool exact_b = ctx->opt[KHG_OPT_K3_PHASE_B] != 1;       // (2 = the fp16 matrix cores where they apply, else fp64)
       // k3_accumulate_wave32: the workgroup's fp64 image + W + two x planes per wave
       const size_t lds32 = sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16) + sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 2 * 16 * 20);
+      // k3_accumulate_wave16: per wave two tiles' phase-A planes + the phase-B planes (halves), then the split W operands
+      const size_t lds16 = std::max<size_t>(2 * (size_t)4 * (2 * (2 * 16 * K3_XH_ROW) + 2 * 2 * 40 * 36) + (size_t)nb * 3 * 2 * 64 * 16,
+                                            sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
 #define K3_WAVE_LAUNCH(NBV)                                                                                            \
   do {                                                                                                                  \
     if (!exact_b && lds32 > 48 * 1024)                                                                                  \
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
-    if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(np, ny), dim3(256), lds, ctx->stream, a);  \
+    if (f16b) {                                                                                                          \
+      HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave16<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
+      hipLaunchKernelGGL((k3_accumulate_wave16<NBV>), dim3(np, ny), dim3(256), lds16, ctx->stream, a);                   \
+    } else if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(np, ny), dim3(256), lds, ctx->stream, a);  \
     else if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(np, ny), dim3(256), lds, ctx->stream, a);       \
     else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(np, ny), dim3(256), lds32, ctx->stream, a);                \
     if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a, ny);                 \

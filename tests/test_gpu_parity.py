@@ -908,3 +908,42 @@ def test_band_loglikes_fill_only_dead_cells_and_align_identically(ctx, opt, beam
         if not want["status"] & 1:
             assert (a == want["ali"]).all(), u
     print(f"beam {beam}: band fill fraction {filled / total:.3f}, {nfb}/{us.n_utt} utterances repaired + decoded order-faithfully")
+
+
+@pytest.mark.parametrize("G,weight", [(64, 1.0), (50, 0.7), (40, 3.0e-4), (64, -2.5)])
+def test_acc_stats_fp16_phase_b_vs_oracle_and_fp64_form(ctx, opt, G, weight):
+    """K3 with phase B on the fp16 matrix cores too (option k3_phase_b = 2; k3_accumulate_wave16): gamma and [x | x^2] split into two
+    fp16 pieces each, three partial products, 32-frame fp32 partial sums added in fp64.  Against the oracle at the tolerance of every
+    other form (2e-5), against the fp64 form much closer (a product carries 22 + 22 bits, 32 of them are summed in fp32: ~1e-7 of the
+    cell's magnitude), occ / transition counts / total log-like computed as in the fp64 form; one block per pdf and slices; weights of
+    any magnitude and sign (the gamma scale 2^SG follows the weight)."""
+    from kaldi_hmm_gmm_amd import DeviceAccs
+
+    m, gc, om, ut, cost = build(20, G, 40, n_utt=80, seed=51 + G, ragged=(G == 50), max_phones=8)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.upload_ali(ut.ref_ali)
+    oa = orc.OAccs(int(m.gauss_off[-1]), m.dim, m.num_tids)
+    for u in range(us.n_utt):
+        orc.acc_stats_ali(om, m.id2pdf, utt_feats(ut, u), ut.ref_ali[ut.frame_off[u]: ut.frame_off[u + 1]], oa, weight=weight)
+    for ny in (1, 5):
+        opt("k3_ny", ny)
+        st = {}
+        for pb in (0, 2):
+            opt("k3_phase_b", pb)
+            runs = []
+            for _ in range(2):
+                accs = DeviceAccs(ctx, dm, tm)
+                us.acc_stats(dm, tm, accs, weight=weight)
+                runs.append(accs.download())
+            for k in ("occ", "mean_acc", "var_acc", "trans_acc"):
+                assert np.array_equal(runs[0][k], runs[1][k]), (pb, k)            # run-to-run reproducible
+            st[pb] = runs[0]
+        a, b = st[0], st[2]
+        assert np.array_equal(a["occ"], b["occ"]) and np.array_equal(a["trans_acc"], b["trans_acc"]) and a["total_frames"] == b["total_frames"]
+        assert b["total_log_like"] == pytest.approx(a["total_log_like"], rel=1e-12)
+        mm, vm = np.abs(a["mean_acc"]).max(), np.abs(a["var_acc"]).max()
+        np.testing.assert_allclose(b["mean_acc"], a["mean_acc"], rtol=2e-6, atol=2e-7 * mm)
+        np.testing.assert_allclose(b["var_acc"], a["var_acc"], rtol=2e-6, atol=2e-7 * vm)
+        np.testing.assert_allclose(b["occ"], oa.occ, rtol=2e-5, atol=1e-6 * abs(weight))
+        np.testing.assert_allclose(b["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.mean_acc).max())
+        np.testing.assert_allclose(b["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
