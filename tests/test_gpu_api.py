@@ -543,7 +543,7 @@ def test_options_are_validated_and_round_trip(ctx):
     old = ctx.set_option("k3_ny", 3)
     assert ctx.get_option("k3_ny") == 3 and ctx.get_option(13) == 3
     assert ctx.set_option(13, old) == 3 and ctx.get_option("k3_ny") == old
-    for name, bad in (("k3_form", 3), ("k1_form", 6), ("k1_order", -1), ("k3_phase_b", 2)):
+    for name, bad in (("k3_form", 3), ("k1_form", 6), ("k1_order", -1), ("k3_phase_b", 3)):
         before = ctx.get_option(name)
         with pytest.raises(khg.KhgError):
             ctx.set_option(name, bad)
