@@ -24,9 +24,13 @@ EMPTY = {"start": -1, "arc_off": np.zeros(1, np.int64), "ilabel": np.zeros(0, np
 
 def fuzz_graphs(ctx, budget=120.0, seed=1):
     rng = np.random.default_rng(seed)
-    t0 = time.time(); n = nutt = nfall = nerr = nret = 0
+    rng_b = np.random.default_rng(seed + 7)      # round 4: which batches also run K1's BAND form (its own stream: the main draws stay as they were)
+    t0 = time.time(); n = nutt = nfall = nerr = nret = nband = 0
     while time.time() - t0 < budget:
         P = int(rng.choice([3, 6, 12, 30])); G = int(rng.choice([1, 3, 8])); D = int(rng.choice([2, 8, 13]))
+        band = rng_b.random() < 0.5
+        if band and rng_b.random() < 0.6:
+            G = int(rng_b.choice([20, 24, 40]))   # pdfs of more than 16 Gaussians: the unpacked kernel, the only one with a band form
         seed = int(rng.integers(1 << 30))
         m = synth.make_model(P, G, D, seed=seed)
         gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
@@ -79,9 +83,18 @@ def fuzz_graphs(ctx, budget=120.0, seed=1):
                 w = res["words"][res["words_off"][u]: res["words_off"][u + 1]]
                 assert (w == want["words"]).all(), (tag, u, "words")
                 assert abs(res["like"][u] - want["like"]) <= 1e-5 * abs(want["like"]) + 1e-4, (tag, u, "like")
+        if band:
+            # K1's BAND form (cells past a pdf's last useful frame filled with an upper bound, khg_align repairing what the DP cannot
+            # certify): the same alignment, status, words and like, bit for bit, on any graph and at any beam
+            us.loglikes(dm, band=True)
+            res2 = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=scale, **kw)
+            assert np.array_equal(res2["ali"], res["ali"]) and np.array_equal(res2["status"] & 3, res["status"] & 3), (tag, "band")
+            assert np.array_equal(res2["words"], res["words"]) and np.array_equal(res2["like"], res["like"]), (tag, "band words / like")
+            nband += 1
         n += 1; nutt += U
         us.close(); tm.close(); dm.close()
-    return {"batches": n, "utterances": nutt, "oracle_failed": int(nerr), "retried": int(nret), "fallback": int(nfall), "seconds": time.time() - t0}
+    return {"batches": n, "utterances": nutt, "oracle_failed": int(nerr), "retried": int(nret), "fallback": int(nfall), "band_batches": int(nband),
+            "seconds": time.time() - t0}
 
 
 def fuzz_parity(ctx, budget=120.0, seed=1):

@@ -1,6 +1,6 @@
 """The randomised sweeps and the larger end-to-end check ON THE RECORD (they only existed as manual scripts):
 seeded, time-boxed slices of tests/fuzzlib.py under `pytest -m gpu`, and the end-to-end mismatch report written to
-profiles/r3_parity_report.json (also gpurun_out/, which is what comes back from the GPU box)."""
+profiles/r4_parity_report.json (also gpurun_out/, which is what comes back from the GPU box)."""
 import json
 import os
 import sys
@@ -22,6 +22,7 @@ def test_fuzz_general_graphs_slice(ctx, seed):
     r = fuzzlib.fuzz_graphs(ctx, budget=15.0, seed=seed)
     assert r["batches"] >= 20 and r["utterances"] >= 100, r
     assert r["fallback"] > 0 and r["retried"] > 0 and r["oracle_failed"] > 0, r      # the slice reaches the order-faithful decoders, retries and failures
+    assert r["band_batches"] >= 5, r                                                 # ... and K1's band form + repair on the same random graphs
 
 
 @pytest.mark.parametrize("seed", [303, 404])
@@ -49,7 +50,7 @@ def test_end_to_end_against_oracle_with_mismatch_report(ctx):
     rep["runs"] += [dict(r, scoring_model=hard["scoring_model"]) for r in hard["runs"]]
     for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
-            with open(os.path.join(d, "r3_parity_report.json"), "w") as fh:
+            with open(os.path.join(d, "r4_parity_report.json"), "w") as fh:
                 json.dump(rep, fh, indent=1)
     assert rep["frames"] > 60000
     for run in rep["runs"]:
