@@ -112,7 +112,9 @@ class ResidentEm:
         if config.careful:
             raise KhgError("ResidentEm.align: careful alignment changes the resident graphs; use align_batch")
         o = decoder_opts or FasterDecoderOptions()
-        self.us.loglikes(self.dm, reachable_only=True)
+        # only the cells a decoder token can read; at a wide beam (few failed beam certificates to repair) also not what only tokens
+        # past any accepting path read (khg_loglikes_band: identical alignments)
+        self.us.loglikes(self.dm, reachable_only=True, band=config.beam >= 100.0)
         r = self.us.align(self.dt, beam=config.beam, retry_beam=config.retry_beam, acoustic_scale=self.acoustic_scale,
                           max_active=o.max_active, min_active=o.min_active, beam_delta=o.beam_delta, hash_ratio=o.hash_ratio,
                           download="summary")
