@@ -153,7 +153,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 2}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
@@ -1671,15 +1671,27 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
                   std::max<size_t>(fast ? 0 : 4 * K2_SB * (max_npdf | 1), tb_bytes) + 64;
   size_t HB = std::max<size_t>(2 * S, 1000);
   size_t lds_f = 32 * S + 8 * HB + 4 * (S + A) + 4 * S + 4 * (S + 1) + 16 * A + A + 64;
-  // Graphs whose decoder tables exceed the 160 KB of LDS (a large decoding graph, not a training graph): the generic DP and
-  // the one-lane order-faithful decoder run with the same tables carved out of an HBM scratch slice per utterance.
-  const bool gmem = lds_dp > 160 * 1024 || lds_f > 160 * 1024;
+  // The order-faithful decoder for the utterances the DP cannot certify: the wave-parallel form with all its tables in LDS; with the
+  // graph tables in an HBM scratch slice per utterance (> ~1600 states on a chain graph); the one-lane form beyond that.
+  // KHG_K2_SERIAL = 1: always the one-lane form; 2: the HBM-graph wave form wherever its per-frame tables fit (tests, A/B).
+  const int odeg_w = u->max_outdeg <= 8 ? std::max(1, (int)u->max_outdeg) : 0;     // 0: exact slot prefix sums
+  const bool use_pos = u->has_eps || S > 1000;
+  const size_t lds_w_mut = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 4 * max_npdf + (odeg_w ? 0 : 4 * A + 4 * S) + (use_pos ? 4 * S : 0) +
+                           (u->has_eps ? 4 * (S + A + 1) : 0) + 8 + 8 * ((std::max(A, S * (size_t)odeg_w) + 63) / 64 + 1);
+  const size_t lds_w_graph = 8 * (S + 1) + 5 * 4 * A + (u->has_eps ? 4 * (S + 1) + 4 * A : 0) + A + S + 64;
+  const int fmode = ctx->opt[KHG_OPT_K2_SERIAL];
+  const bool wave_lds = fmode == 0 && S <= 65535 && lds_w_mut + lds_w_graph <= 160 * 1024;
+  const bool wave_gm = fmode != 1 && !wave_lds && S <= 65535 && lds_w_mut <= 160 * 1024;
+  const bool lane_gm = !wave_lds && !wave_gm && lds_f > 160 * 1024;
+  // Graphs whose DP tables exceed the 160 KB of LDS (a large decoding graph, not a training graph): the generic DP runs with its
+  // tables carved out of the same HBM scratch slice.
+  const bool gmem = lds_dp > 160 * 1024;
   a.gscratch = nullptr; a.gscratch_stride = 0;
-  if (gmem) {
-    // (the generic DP's carve-up: no register-resident path)
+  if (gmem) // (the generic DP's carve-up: no register-resident path)
     lds_dp = 16 * S + 8 * K2_MAXW + 8 * A + 4 * (S + 1) + 8 * K2_FB * nwave + 32 + 8 * K2_MAXW + 16 +
              std::max<size_t>(4 * K2_SB * (max_npdf | 1), (K2_FB + 1) * ((S + 15) & ~size_t(15))) + 64;
-    const size_t stride = (std::max(lds_dp, lds_f) + 255) & ~size_t(255);
+  if (gmem || wave_gm || lane_gm) {
+    const size_t stride = (std::max(gmem ? lds_dp : 0, std::max(wave_gm ? lds_w_graph : 0, lane_gm ? lds_f : 0)) + 255) & ~size_t(255);
     const size_t need = stride * (size_t)u->n_utt;
     if (need > u->k2_gscratch_bytes) {
       DEVFREE(u->k2_gscratch_d);
@@ -1687,6 +1699,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
       u->k2_gscratch_bytes = need;
     }
     a.gscratch = u->k2_gscratch_d; a.gscratch_stride = (int64_t)stride;
+  }
+  if (gmem) {
     KernelTimer kt(ctx, "k2_viterbi_dp");
     hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false, true>), dim3(u->n_utt), dim3(nthr), 0, ctx->stream, a);
   } else {
@@ -1700,7 +1714,6 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
                        sc3 ? (const void*)k2_viterbi_dp<1, 3, true, false, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
                      : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
     if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
-    if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     KernelTimer kt(ctx, "k2_viterbi_dp");
     if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
     else if (sc2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true, false, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
@@ -1737,19 +1750,17 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   }
   {
     KernelTimer kt(ctx, "k2_viterbi_faithful", side);
-    // wave-parallel form for graphs of <= 1000 states (any out-degree, epsilon-input arcs handled by a lane-0 worklist over
-    // the epsilon-capable tokens only); the one-lane form handles larger graphs and the HBM-scratch case
-    const int odeg_w = u->max_outdeg <= 8 ? std::max(1, (int)u->max_outdeg) : 0;     // 0: exact slot prefix sums
-    const size_t lds_w = 16 * S + 8 * S + 4 * 4 * S + 4 * S + 8 * (S + 1) + 5 * 4 * A + 4 * max_npdf +
-                         (odeg_w ? 0 : 4 * A + 4 * S) + (u->has_eps ? 4 * S + 4 * (S + A + 1) + 4 * (S + 1) + 4 * A : 0) + 8 +
-                         8 * ((std::max(A, S * (size_t)odeg_w) + 63) / 64 + 1) + A + S + 64;
-    const bool wave_ok = !gmem && S <= 1000 && lds_w <= 160 * 1024 && !ctx->opt[KHG_OPT_K2_SERIAL];
-    if (wave_ok) {
-      if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
-      hipLaunchKernelGGL(k2_viterbi_faithful_wave, dim3(u->n_utt), dim3(64), lds_w, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
-    } else if (gmem) {
+    if (wave_gm) {
+      if (lds_w_mut > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w_mut));
+      hipLaunchKernelGGL(k2_viterbi_faithful_wave<true>, dim3(u->n_utt), dim3(64), lds_w_mut, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
+    } else if (wave_lds) {
+      const size_t lds_w = lds_w_mut + lds_w_graph;
+      if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+      hipLaunchKernelGGL(k2_viterbi_faithful_wave<false>, dim3(u->n_utt), dim3(64), lds_w, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
+    } else if (lane_gm) {
       hipLaunchKernelGGL(k2_viterbi_faithful<true>, dim3(u->n_utt), dim3(64), 0, side, a);
     } else {
+      if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       hipLaunchKernelGGL(k2_viterbi_faithful<false>, dim3(u->n_utt), dim3(64), lds_f, side, a);
     }
   }

@@ -38,6 +38,22 @@ def random_graph(rng, num_tids, n_main=8, p_branch=0.3, p_eps=0.2, with_final=Tr
     }
 
 
+def permute_states(g, rng):
+    """The same graph with its states renumbered at random (arc order inside a state kept): what a compiled graph's numbering
+    looks like to a hash table keyed by the state id."""
+    S = len(g["final"])
+    perm = rng.permutation(S)                              # old -> new
+    inv = np.argsort(perm)                                 # new -> old
+    deg = np.diff(g["arc_off"])
+    arc_off = np.concatenate([[0], np.cumsum(deg[inv])]).astype(np.int64)
+    idx = np.concatenate([np.arange(g["arc_off"][o], g["arc_off"][o + 1]) for o in inv]) if S else np.zeros(0, np.int64)
+    out = {"start": int(perm[g["start"]]), "arc_off": arc_off, "final": g["final"][inv]}
+    for k in ("ilabel", "olabel", "weight"):
+        out[k] = g[k][idx]
+    out["nextstate"] = perm[g["nextstate"][idx]].astype(np.int32)
+    return out
+
+
 def concat(gs):
     out = {"state_off": [0], "start": [], "arc_off": [np.zeros(1, np.int64)]}
     for k in ("ilabel", "olabel", "weight", "nextstate", "final"):

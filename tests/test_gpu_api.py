@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from graphs import concat, hub_graph, random_graph
+from graphs import concat, hub_graph, permute_states, random_graph
 from helpers import build, oracle_graph, utt_feats
 from oracle import oracle as orc
 
@@ -455,6 +455,63 @@ def test_wave_faithful_decoder_epsilon_arcs_and_wide_fanout_equal_serial_and_ora
                 w = rw["words"][rw["words_off"][u]: rw["words_off"][u + 1]]
                 assert (w == want["words"]).all(), (kw, u)
     assert seen > 100, "the order-faithful decoder was hardly exercised"
+
+
+@pytest.mark.parametrize("sizes", [((1100, 0.0), (1500, 0.0), (1300, 0.2), (40, 0.0)), ((2300, 0.0), (1900, 0.3), (1200, 0.0))])
+def test_wave_faithful_decoder_above_1000_states_shared_hash_buckets(ctx, opt, sizes):
+    """Graphs of more than 1000 states with state numbers in random order: states s and s + k hash_size share a bucket of the
+    reference's HashList, so the token list is no longer in insertion order (hash-list-inl.h:129-174; the hash size follows
+    faster-decoder.cc:337-344 and never shrinks).  The wave-parallel decoder (all tables in LDS; graph tables in HBM scratch --
+    the second set only fits that way, the first is forced into it with k2_serial = 2) against the one-lane emulation and the
+    oracle's FasterDecoder, with every state alive (max_active set: no beam certificate) and with beams that prune."""
+    from kaldi_hmm_gmm_amd import synth
+
+    rng = np.random.default_rng(1234 + len(sizes))
+    m = synth.make_model(30, 2, 6, seed=9)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    graphs = [permute_states(random_graph(rng, m.num_tids, n_main=n, p_eps=pe, p_branch=0.4), rng) for n, pe in sizes]
+    for g in graphs:          # weights and scores on one coarse grid: equal-cost tokens everywhere, so WHICH path wins depends on the list order
+        g["weight"] = (np.round(g["weight"] * 4) / 4).astype(np.float32)
+    T = [int(1.45 * n) + int(rng.integers(10, 120)) for n, _ in sizes]
+    frame_off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+    feats = (rng.standard_normal((frame_off[-1], 6)) * 3).astype(np.float32)
+
+    class UT:
+        pass
+    ut = UT(); ut.frame_off = frame_off; ut.feats = feats; ut.graphs = concat(graphs)
+    cost = np.zeros(m.num_tids + 1, np.float32)
+    dm, tm, us = _dev(ctx, m, gc, ut, cost)
+    poff, pdfs = us.pdf_lists()
+    mats = [(-0.25 * rng.integers(0, 24, size=(poff[u + 1] - poff[u], T[u]))).astype(np.float32) for u in range(us.n_utt)]
+    us.upload_loglikes(mats)
+    seen = 0
+    ok = 0
+    for kw in (dict(beam=200.0, retry_beam=0.0, max_active=100000), dict(beam=40.0, retry_beam=0.0, max_active=700, min_active=3),
+               dict(beam=20.0, retry_beam=60.0, min_active=0), dict(beam=60.0, retry_beam=0.0, max_active=100000, hash_ratio=1.0)):
+        res = {}
+        for mode in (0, 2, 1):
+            opt("k2_serial", mode)
+            res[mode] = us.align(tm, acoustic_scale=1.0, **kw)
+        rw = res[0]
+        for mode in (2, 1):
+            assert np.array_equal(rw["status"], res[mode]["status"]), (kw, mode)
+            assert np.array_equal(rw["ali"], res[mode]["ali"]), (kw, mode)
+            assert np.array_equal(rw["words"], res[mode]["words"]) and np.array_equal(rw["words_off"], res[mode]["words_off"]), (kw, mode)
+            np.testing.assert_array_equal(rw["like"], res[mode]["like"])
+        seen += int(((rw["status"] & 8) != 0).sum())
+        for u, g in enumerate(graphs):
+            og = orc.OGraph(g["start"], g["arc_off"], g["ilabel"], g["olabel"], g["weight"], g["nextstate"], g["final"])
+            want = orc.align_utterance_ll(og, m.id2pdf, T[u], pdfs[poff[u]: poff[u + 1]], mats[u], acoustic_scale=1.0, **kw)
+            assert (int(rw["status"][u]) & 3) == (want["status"] & 3), (kw, u)
+            a = rw["ali"][frame_off[u]: frame_off[u + 1]]
+            if not (want["status"] & 1):
+                ok += 1
+                assert (a == want["ali"]).all(), (kw, u)
+                w = rw["words"][rw["words_off"][u]: rw["words_off"][u + 1]]
+                assert (w == want["words"]).all(), (kw, u)
+    assert seen >= 3 * len(sizes) and ok >= 3 * len(sizes), "the order-faithful decoder was hardly exercised"
+    for o in (us, tm, dm):
+        o.close()
 
 
 def test_accs_as_torch_aliases_the_device_block_and_all_reduces(ctx):
