@@ -47,6 +47,9 @@ def parse():
                          "products); bf16x3 = bf16 matrix cores, 6 partial products; pdf / utt = the fp32-MFMA forms")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the two extra steps that time the fp32-MFMA K1 beside an f16x2 / bf16x3 run")
     ap.add_argument("--seed", type=int, default=20230418)
+    ap.add_argument("--transcripts", choices=["uniform", "zipf"], default="uniform",
+                    help="phone sequences: independent uniform phones (BASELINE.json's synthetic set) or running text from a Zipf lexicon "
+                         "(utterances share pdfs the way real transcripts do: synth.zipf_phone_stream)")
     ap.add_argument("--allreduce", choices=["khg", "torch", "khg-f32", "host"], default="khg",
                     help="C1: khg = khg_accs_allreduce (RCCL called by the library on the kernels' stream); torch = "
                          "torch.distributed.all_reduce on a view of the block; khg-f32 = the fp32-wire tolerance experiment; "
@@ -344,7 +347,7 @@ def main():
     # ONE utterance set, whatever N: every rank builds the whole (feature-less) set from the N = 1 seeds, keeps the
     # utterances shard_utterances deals it, and draws the one global feature stream storing only its own frames
     from kaldi_hmm_gmm_amd.dist import make_comm, shard_utterances, take_utterances
-    ut_all = synth.make_utts(model, args.utts, seed=args.seed + 1000, feats=False)
+    ut_all = synth.make_utts(model, args.utts, seed=args.seed + 1000, feats=False, transcripts=args.transcripts)
     dev = torch.device("cuda", local)
     if world > 1:
         mine = shard_utterances(np.diff(ut_all.frame_off), world)[rank]
@@ -734,7 +737,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} pdfs x {G} Gauss, dim {D}, {args.utts} utterances "
                                    f"({frames_total} frames) sharded over {world} GPU(s), beam {args.beam:g}, "
-                                   f"acoustic_scale 0.1, mean pdfs/utt {npdf.mean():.1f}",
+                                   f"acoustic_scale 0.1, mean pdfs/utt {npdf.mean():.1f}" + (", Zipf-lexicon transcripts" if args.transcripts == "zipf" else ""),
                        "frames_per_step": frames_total, "utterances": args.utts},
             "roofline": roofline,
             "fp32_mfma_line": fp32_line,

@@ -214,6 +214,7 @@ static int check_err_flag(khg_ctx* c, const char* where) {
     HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
     if (f & 1) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": Invalid answer (overflow or invalid variances/features?)");
     if (f & 2) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": internal queue overflow in the faithful decoder");
+    if (f & 8) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": internal error: K3 work items exceed their bound");
     return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": pdf-id out of range (graph/model mismatch)");
   }
   return KHG_OK;
@@ -531,6 +532,7 @@ struct khg_utts {
   uint32_t *sort_keys_d = nullptr, *sort_keys_out_d = nullptr, *sort_vals_d = nullptr; void* sort_tmp_d = nullptr; size_t sort_tmp_bytes = 0;
   int32_t* cs_hist_d = nullptr; size_t cs_hist_n = 0; int64_t* cs_tot_d = nullptr; size_t cs_tot_n = 0;   // counting-sort bucketing (k3_cs_*)
   double *k3_part_d = nullptr, *k3_llpart_d = nullptr; size_t k3_part_n = 0, k3_llpart_n = 0;   // wave-form K3: slice images / per-pdf log-likes
+  void* k3_items_d = nullptr; int32_t* k3_item_off_d = nullptr; size_t k3_items_n = 0, k3_item_off_n = 0;   // K3 work items (k3_make_items)
   int64_t* pdf_start_d = nullptr; unsigned long long* tid_count_d = nullptr;
   int32_t k3_P = 0, k3_tids = 0;
 };
@@ -779,7 +781,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
   DEVFREE(u->sort_keys_d); DEVFREE(u->sort_keys_out_d); DEVFREE(u->sort_vals_d); DEVFREE(u->sort_tmp_d); DEVFREE(u->cs_hist_d); DEVFREE(u->cs_tot_d);
-  DEVFREE(u->k3_part_d); DEVFREE(u->k3_llpart_d);
+  DEVFREE(u->k3_part_d); DEVFREE(u->k3_llpart_d); DEVFREE(u->k3_items_d); DEVFREE(u->k3_item_off_d);
   if (u->ev_dp) (void)hipEventDestroy(u->ev_dp);
   if (u->ev_ali) (void)hipEventDestroy(u->ev_ali);
   delete u;
@@ -1976,7 +1978,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
   a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
   a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
   a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
-  a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr; a.pdf0 = 0;
+  a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr; a.pdf0 = 0; a.npdf = m->P; a.items = nullptr; a.item_off = nullptr;
   a.pa_ex = nullptr; a.pa_S = 0; a.pa_scale = 1.0f; a.pa_inv = 1.0f; a.pa_c1 = 1.44269504088896340736f;
   nparts = std::max(1, std::min(nparts, m->P));
   if (comm && nparts > 1) { rc = ctx_comm_stream(ctx); if (rc) return rc; }
@@ -2039,6 +2041,40 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         hipLaunchKernelGGL(k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
       }
     }
+    // Work items of the accumulate kernels (k3_make_items): ny_base slices per pdf, more for a pdf whose bucket is far above the
+    // average slice (2 x; silence in real transcripts).  -> the number of blocks to launch for a range of np pdfs (an upper bound
+    // from N and P alone: the bucket sizes stay on the device) in *extra_blocks; parked: the slices park images (wave forms).
+    int64_t k3_extra_blocks = 0;
+    auto make_items = [&](int ny_base, bool parked, size_t nsum1) -> int {
+      const int64_t avg = u->N / std::max(1, m->P);
+      const int target = (int)std::min<int64_t>(1 << 30, std::max<int64_t>(512, 2 * avg / ny_base));
+      const int64_t per_t = u->N / target;
+      k3_extra_blocks = std::min<int64_t>(per_t + m->P, 2 * per_t) + 1;
+      const int64_t max_items = (int64_t)m->P * ny_base + k3_extra_blocks;
+      const int64_t max_slots = !parked ? INT_MAX : ny_base > 1 ? max_items : 2 * per_t + 1;
+      if (max_items >= INT_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: too many work items");
+      if (u->k3_items_n < (size_t)max_items) {
+        DEVFREE(u->k3_items_d);
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&u->k3_items_d), sizeof(K3Item) * (size_t)max_items));
+        u->k3_items_n = (size_t)max_items;
+      }
+      if (u->k3_item_off_n < (size_t)m->P + 1) {
+        DEVFREE(u->k3_item_off_d);
+        int rc2 = dev_alloc(&u->k3_item_off_d, (size_t)m->P + 1);
+        if (rc2) return rc2;
+        u->k3_item_off_n = (size_t)m->P + 1;
+      }
+      if (parked && u->k3_part_n < (size_t)max_slots * nsum1) {
+        DEVFREE(u->k3_part_d);
+        int rc2 = dev_alloc(&u->k3_part_d, (size_t)max_slots * nsum1);
+        if (rc2) return rc2;
+        u->k3_part_n = (size_t)max_slots * nsum1;
+      }
+      hipLaunchKernelGGL(k3_make_items, dim3(1), dim3(1024), 0, ctx->stream, a, ny_base, target, (int)max_items, (int)std::min<int64_t>(max_slots, INT_MAX),
+                         reinterpret_cast<K3Item*>(u->k3_items_d), u->k3_item_off_d);
+      a.items = reinterpret_cast<const K3Item*>(u->k3_items_d); a.item_off = u->k3_item_off_d;
+      return KHG_OK;
+    };
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
     const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
@@ -2077,18 +2113,15 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         if (rc) return rc;
         u->k3_llpart_n = (size_t)m->P;
       }
-      if (ny > 1 && u->k3_part_n < (size_t)m->P * ny * nsum1) {
-        DEVFREE(u->k3_part_d);
-        rc = dev_alloc(&u->k3_part_d, (size_t)m->P * ny * nsum1);
-        if (rc) return rc;
-        u->k3_part_n = (size_t)m->P * ny * nsum1;
-      }
+      rc = make_items(ny, true, nsum1);
+      if (rc) return rc;
       HIPCHK(hipMemsetAsync(u->k3_llpart_d, 0, sizeof(double) * (size_t)m->P, ctx->stream));
       a.ll_part = u->k3_llpart_d;
-      a.part = ny > 1 ? u->k3_part_d : nullptr;
+      a.part = u->k3_part_d;
       for (int part = 0; part < nparts; ++part) {
       const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
-      a.pdf0 = p0;
+      a.pdf0 = p0; a.npdf = np;
+      const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
       {
       KernelTimer kt(ctx, "k3_accumulate");
       // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
@@ -2105,11 +2138,11 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
     if (f16b) {                                                                                                          \
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave16<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
-      hipLaunchKernelGGL((k3_accumulate_wave16<NBV>), dim3(np, ny), dim3(256), lds16, ctx->stream, a);                   \
-    } else if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(np, ny), dim3(256), lds, ctx->stream, a);  \
-    else if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(np, ny), dim3(256), lds, ctx->stream, a);       \
-    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(np, ny), dim3(256), lds32, ctx->stream, a);                \
-    if (ny > 1) hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a, ny);                 \
+      hipLaunchKernelGGL((k3_accumulate_wave16<NBV>), dim3(nblk), dim3(256), lds16, ctx->stream, a);                     \
+    } else if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);    \
+    else if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(nblk), dim3(256), lds, ctx->stream, a);         \
+    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(nblk), dim3(256), lds32, ctx->stream, a);                  \
+    hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a);                                 \
   } while (0)
       switch (nb) {
         case 1: K3_WAVE_LAUNCH(1); break;
@@ -2121,7 +2154,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       }
       if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }
-      a.pdf0 = 0;
+      a.pdf0 = 0; a.npdf = m->P;
       hipLaunchKernelGGL(k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
     } else if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
@@ -2130,17 +2163,20 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
       if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
+      rc = make_items(ny, false, 0);
+      if (rc) return rc;
       for (int part = 0; part < nparts; ++part) {
         const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
-        a.pdf0 = p0;
+        a.pdf0 = p0; a.npdf = np;
+        const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, "k3_accumulate");
-          if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10 && maxG <= 128) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10 && maxG <= 192) hipLaunchKernelGGL((k3_accumulate_mfma<10, 3>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 4>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 128) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 192) hipLaunchKernelGGL((k3_accumulate_mfma<10, 3>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 4>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
         }
         if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }
@@ -2151,14 +2187,17 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : m->KQ == 20 ? (const void*)k3_accumulate<20> : (const void*)k3_accumulate<0>;
       if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
+      rc = make_items(ny, false, 0);
+      if (rc) return rc;
       for (int part = 0; part < nparts; ++part) {
         const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
-        a.pdf0 = p0;
+        a.pdf0 = p0; a.npdf = np;
+        const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, "k3_accumulate");
-          if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 20) hipLaunchKernelGGL(k3_accumulate<20>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
-          else hipLaunchKernelGGL(k3_accumulate<0>, dim3(np, ny), dim3(256), lds, ctx->stream, a);
+          if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 20) hipLaunchKernelGGL(k3_accumulate<20>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL(k3_accumulate<0>, dim3(nblk), dim3(256), lds, ctx->stream, a);
         }
         if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }

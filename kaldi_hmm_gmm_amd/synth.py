@@ -96,9 +96,33 @@ class SynthUtts:
     num_phones: np.ndarray  # [U]
 
 
+def zipf_phone_stream(rng, nphones, n, vocab=20000, exponent=1.0, sil_prob=0.2):
+    """n phones of running text: words drawn from a lexicon of `vocab` words (2..8 phones each, fixed per word) with Zipf
+    frequencies rank^-exponent, phone 0 (silence) between two words with probability sil_prob.  Utterances cut from this stream
+    share pdfs the way real transcripts do (frequent words, silence), unlike independent uniform phones."""
+    wlen = rng.integers(2, 9, size=vocab)
+    woff = np.concatenate([[0], np.cumsum(wlen)])
+    wphones = rng.integers(1 if nphones > 1 else 0, nphones, size=int(woff[-1]))
+    p = 1.0 / np.arange(1, vocab + 1) ** exponent
+    nw = n // 2 + 2                                       # words of >= 2 phones: enough for n phones
+    words = rng.choice(vocab, size=nw, p=p / p.sum())
+    sil = rng.random(nw) < sil_prob
+    seg = wlen[words] + sil                               # phones per word incl. its leading silence
+    start = np.concatenate([[0], np.cumsum(seg)])[:-1]
+    total = int(seg.sum())
+    pos = np.arange(total) - np.repeat(start, seg)        # position inside the segment
+    w_of = np.repeat(words, seg)
+    s_of = np.repeat(sil, seg)
+    idx = woff[w_of] + np.maximum(pos - s_of, 0)
+    out = np.where(s_of & (pos == 0), 0, wphones[idx])
+    return out[:n]
+
+
 def make_utts(model: SynthModel, n_utt, seed=1, min_phones=10, max_phones=40, leave_prob=0.25, feats=True,
-              shuffle_phones=True):
-    """Utterances of L ~ U{min..max} phones x 3 HMM states; state durations 1 + Geom(leave_prob)."""
+              shuffle_phones=True, transcripts="uniform"):
+    """Utterances of L ~ U{min..max} phones x 3 HMM states; state durations 1 + Geom(leave_prob).
+    transcripts: "uniform" = independent uniform phones; "zipf" = running text from a Zipf lexicon (zipf_phone_stream);
+    "skew" = uniform, but every second phone is phone 0."""
     rng = np.random.default_rng(seed)
     P = model.num_pdfs
     nphones = P // 3
@@ -106,7 +130,12 @@ def make_utts(model: SynthModel, n_utt, seed=1, min_phones=10, max_phones=40, le
     L = rng.integers(min_phones, max_phones + 1, size=n_utt)
     nst = 3 * L                                   # emitting HMM states per utterance
     tot_states = int(nst.sum())
-    phones = rng.integers(0, nphones, size=int(L.sum()))
+    if transcripts == "zipf":
+        phones = zipf_phone_stream(rng, nphones, int(L.sum()))
+    else:
+        phones = rng.integers(0, nphones, size=int(L.sum()))
+        if transcripts == "skew":                  # half of all phones are phone 0: its pdfs hold many times the average pdf's frames
+            phones = np.where(rng.random(phones.shape[0]) < 0.5, 0, phones)
     state_pdf = (3 * np.repeat(phones, 3) + np.tile(np.arange(3), phones.shape[0])).astype(np.int32)
     dur = rng.geometric(leave_prob, size=tot_states).astype(np.int64)  # >= 1
     st_off = np.concatenate([[0], np.cumsum(nst)])

@@ -5,11 +5,11 @@ from kaldi_hmm_gmm_amd import synth
 from oracle import oracle as orc
 
 
-def build(num_pdfs, gauss, dim, n_utt, seed=1, ragged=False, min_phones=2, max_phones=6, tscale=1.0, slscale=0.1):
+def build(num_pdfs, gauss, dim, n_utt, seed=1, ragged=False, min_phones=2, max_phones=6, tscale=1.0, slscale=0.1, transcripts="uniform"):
     m = synth.make_model(num_pdfs, gauss, dim, seed=20230414 + seed, ragged=ragged)
     gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
     om = orc.OModel(m.gauss_off, gc, m.means_invvars, m.inv_vars)
-    ut = synth.make_utts(m, n_utt, seed=seed, min_phones=min_phones, max_phones=max_phones)
+    ut = synth.make_utts(m, n_utt, seed=seed, min_phones=min_phones, max_phones=max_phones, transcripts=transcripts)
     # what AddTransitionProbs adds per tid, from the oracle (hmm-utils.cc:442-463)
     il = np.arange(m.num_tids + 1, dtype=np.int32)
     cost = orc.add_transition_probs(il, np.zeros(m.num_tids + 1, np.float32), m.log_probs, m.non_self_loop_log_probs,

@@ -403,6 +403,48 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
     np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
 
 
+@pytest.mark.parametrize("k3_form", ["wave", "wave_b64", "wave_f32", "block", "valu"])
+@pytest.mark.parametrize("P,G,D", [(60, 64, 40), (300, 24, 39)])
+def test_acc_stats_with_a_pdf_far_above_the_average(ctx, P, G, D, k3_form, opt):
+    """Half of all phones are phone 0 (silence in real transcripts): its three pdfs hold ~15x / ~50x the frames of an average pdf, so
+    k3_make_items cuts their buckets into more slices than the other pdfs' (one block per pdf would leave the chip waiting for three
+    blocks).  Every K3 form against the oracle, and bit-reproducible run to run (slices are parked and added in slice order)."""
+    from kaldi_hmm_gmm_amd import DeviceAccs
+
+    if k3_form == "wave_b64":
+        opt("k3_phase_b", 0)
+    if k3_form == "wave_f32":
+        opt("k3_phase_a", 1)
+    if k3_form == "block":
+        opt("k3_form", 1)
+    elif k3_form == "valu":
+        opt("k3_form", 2)
+    m, gc, om, ut, cost = build(P, G, D, n_utt=60, seed=11, min_phones=20, max_phones=40, transcripts="skew")
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.upload_ali(ut.ref_ali)
+    per_pdf = np.bincount(m.id2pdf[ut.ref_ali], minlength=P)
+    assert per_pdf[:3].min() > 8 * per_pdf.mean()
+    accs = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs, weight=1.0)
+    got = accs.download()
+    oa = orc.OAccs(int(m.gauss_off[-1]), D, m.num_tids)
+    for u in range(us.n_utt):
+        orc.acc_stats_ali(om, m.id2pdf, utt_feats(ut, u), ut.ref_ali[ut.frame_off[u]: ut.frame_off[u + 1]], oa)
+    assert (got["trans_acc"] == oa.trans_acc).all() and got["total_frames"] == oa.total_frames
+    assert got["total_log_like"] == pytest.approx(oa.total_log_like, rel=2e-6)
+    np.testing.assert_allclose(got["occ"], oa.occ, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.mean_acc).max())
+    np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
+    per_gauss = np.add.reduceat(got["occ"], m.gauss_off[:-1].astype(np.int64))
+    np.testing.assert_allclose(per_gauss, per_pdf, rtol=1e-5, atol=1e-4)
+    if k3_form.startswith("wave"):              # the block / VALU forms end in fp64 atomics: sums in any order
+        accs2 = DeviceAccs(ctx, dm, tm)
+        us.acc_stats(dm, tm, accs2, weight=1.0)
+        again = accs2.download()
+        for k in ("occ", "mean_acc", "var_acc", "trans_acc"):
+            assert np.array_equal(got[k], again[k]), k
+
+
 @pytest.mark.parametrize("phase_b", [0, 2])
 @pytest.mark.parametrize("overlap", [False, True])
 def test_acc_stats_fp16_phase_a_against_fp64_posteriors_and_sharding(ctx, opt, overlap, phase_b):
