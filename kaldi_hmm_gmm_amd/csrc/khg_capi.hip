@@ -2035,7 +2035,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
           u->sort_tmp_bytes = need;
         }
         if (tm->num_tids <= K3_LDS_TIDS) hipLaunchKernelGGL(k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
-        else hipLaunchKernelGGL(k3_sort_keys<false>, dim3(gb), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        else hipLaunchKernelGGL(k3_sort_keys<false>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
                                                   reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
         hipLaunchKernelGGL(k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
