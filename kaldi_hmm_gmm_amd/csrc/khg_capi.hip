@@ -1712,19 +1712,31 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     // (KHG_K2_KS = 3: the general three-slot kernel, for the A/B)
     const bool sc2 = deg2 && u->same_col;     // ... and one score row per state: one score block / cost conversion per state
     const bool sc3 = fast && !deg6 && !deg2 && KSsel == 1 && u->same_col && ctx->opt[KHG_OPT_K2_KS] != 3;   // three slots, one score row per state
-    const void* k2fn = deg6 ? (const void*)k2_viterbi_dp<1, 6, true> : sc2 ? (const void*)k2_viterbi_dp<1, 2, true, false, true> : deg2 ? (const void*)k2_viterbi_dp<1, 2, true> :
-                       sc3 ? (const void*)k2_viterbi_dp<1, 3, true, false, true> : KSsel == 1 ? (const void*)k2_viterbi_dp<1, 3, true> : KSsel == 2 ? (const void*)k2_viterbi_dp<2, 3, true>
-                     : KSsel == 4 ? (const void*)k2_viterbi_dp<4, 3, true> : (const void*)k2_viterbi_dp<1, 1, false>;
-    if (lds_dp > 48 * 1024) HIPCHK(hipFuncSetAttribute(k2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp));
+    // Two / four states per thread (graphs of more than 1024 / 2048 states): a block of 1024 threads leaves 128 registers per lane;
+    // the three-slot form needs ~180 at two states per thread (84 registers spilled at the one-state kernels' budget of 96: a
+    // transcript of > 340 phones ran 9x slower per frame than one of 330), the two-slot forms of chain graphs fit (round 4)
+    const bool deg2m = fast && !deg6 && KSsel > 1 && u->max_indeg <= 2;
+#define K2_DP_CASES(X)                                                                                         \
+    if (deg6) X((k2_viterbi_dp<1, 6, true>));                                                                  \
+    else if (sc2) X((k2_viterbi_dp<1, 2, true, false, true>));                                                 \
+    else if (deg2) X((k2_viterbi_dp<1, 2, true>));                                                             \
+    else if (sc3) X((k2_viterbi_dp<1, 3, true, false, true>));                                                 \
+    else if (KSsel == 1) X((k2_viterbi_dp<1, 3, true>));                                                       \
+    else if (KSsel == 2 && deg2m && u->same_col) X((k2_viterbi_dp<2, 2, true, false, true>));                  \
+    else if (KSsel == 2 && deg2m) X((k2_viterbi_dp<2, 2, true>));                                              \
+    else if (KSsel == 2) X((k2_viterbi_dp<2, 3, true>));                                                       \
+    else if (KSsel == 4 && deg2m && u->same_col) X((k2_viterbi_dp<4, 2, true, false, true>));                  \
+    else if (KSsel == 4 && deg2m) X((k2_viterbi_dp<4, 2, true>));                                              \
+    else if (KSsel == 4) X((k2_viterbi_dp<4, 3, true>));                                                       \
+    else X((k2_viterbi_dp<1, 1, false>));
+#define K2_SET_LDS(FN) HIPCHK(hipFuncSetAttribute((const void*)FN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp))
+#define K2_LAUNCH(FN) hipLaunchKernelGGL(FN, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a)
+    if (lds_dp > 48 * 1024) { K2_DP_CASES(K2_SET_LDS) }
     KernelTimer kt(ctx, "k2_viterbi_dp");
-    if (deg6) hipLaunchKernelGGL((k2_viterbi_dp<1, 6, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else if (sc2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true, false, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else if (deg2) hipLaunchKernelGGL((k2_viterbi_dp<1, 2, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else if (sc3) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true, false, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else if (KSsel == 1) hipLaunchKernelGGL((k2_viterbi_dp<1, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else if (KSsel == 2) hipLaunchKernelGGL((k2_viterbi_dp<2, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else if (KSsel == 4) hipLaunchKernelGGL((k2_viterbi_dp<4, 3, true>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
-    else hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false>), dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a);
+    K2_DP_CASES(K2_LAUNCH)
+#undef K2_LAUNCH
+#undef K2_SET_LDS
+#undef K2_DP_CASES
   }
   HIPCHK(hipGetLastError());
   if (!u->ev_dp) { HIPCHK(hipEventCreateWithFlags(&u->ev_dp, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&u->ev_ali, hipEventDisableTiming)); }

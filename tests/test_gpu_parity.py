@@ -716,6 +716,18 @@ def test_align_graphs_beyond_1024_states(ctx):
         assert want["status"] & 1 == 0 and int(res["status"][u]) & 1 == 0
         assert (res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]] == want["ali"]).all()
         assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
+    # four states per thread, tables still in LDS
+    m, gc, om, ut, cost = build(90, 2, 13, n_utt=2, seed=700, min_phones=700, max_phones=730)
+    S = int(np.diff(ut.graphs["state_off"]).max())
+    assert 2048 < S <= 2200
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm, reachable_only=True)
+    res = us.align(tm, beam=200.0, acoustic_scale=0.1)
+    for u in range(us.n_utt):
+        want = orc.align_utterance(oracle_graph(ut, u, cost), om, m.id2pdf, utt_feats(ut, u), acoustic_scale=0.1)
+        assert want["status"] & 1 == 0 and int(res["status"][u]) & 1 == 0 and int(res["status"][u]) & 4
+        assert (res["ali"][ut.frame_off[u]: ut.frame_off[u + 1]] == want["ali"]).all()
+        assert res["like"][u] == pytest.approx(want["like"], rel=2e-5)
     m, gc, om, ut, cost = build(90, 2, 13, n_utt=1, seed=900, min_phones=900, max_phones=910)
     assert int(np.diff(ut.graphs["state_off"]).max()) > 2500
     dm, tm, us = _device(ctx, m, gc, ut, cost)
