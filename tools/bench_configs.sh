@@ -14,3 +14,7 @@ python bench.py --utts 12500 --no-cpu-baseline --no-fp32-line 2>/dev/null | pyth
 import json,sys
 d=json.loads(sys.stdin.read().splitlines()[-1]); k=d['kernel_ms_per_step']
 print('8-GPU shard size (12500 utts)', 'value %.1f M  step %.2f ms' % (d['value']/1e6, d['ms_per_step']), {a: round(b,2) for a,b in k.items()})"
+python bench.py --transcripts zipf --no-cpu-baseline --no-fp32-line 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().splitlines()[-1]); k=d['kernel_ms_per_step']
+print('tri5000x64, Zipf-lexicon transcripts', 'value %.1f M  step %.2f ms' % (d['value']/1e6, d['ms_per_step']), {a: round(b,2) for a,b in k.items()})"
