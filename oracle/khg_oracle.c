@@ -7,7 +7,8 @@
  * tests accept 1e-4 on these quantities (python/tests/test_diag_gmm.py:342-349).
  *
  * FasterDecoder / AlignUtteranceWrapper / M-step: "PARITY UNPINNED" (no known-answer test in
- * the reference; reference not buildable offline) -- line-faithful restatement only.
+ * the reference; reference not buildable offline) -- line-faithful restatement only; the
+ * decoder's HashList alone is pinned by the reference's own header (oracle/_ref, see khg_oracle.h).
  *
  * Build: gcc -O2 -ffp-contract=off (no -ffast-math: float/double rounding points matter).
  */
@@ -809,6 +810,12 @@ int64_t orc_hl_clear_reinsert(void *h, int64_t new_size, int32_t shift) {
     hl_delete(d, e);
   }
   return n;
+}
+
+/* Clear() and Delete() of every element: what the decoder does with a frame's list once it is expanded (faster-decoder.cc:158, :240) */
+void orc_hl_drop(void *h) {
+  Decoder *d = (Decoder *)h;
+  for (Elem *e = hl_clear(d), *t; e != NULL; e = t) { t = e->tail; hl_delete(d, e); }
 }
 
 /* decoder-wrappers.cc:16-108 with faster-decoder.cc:355-423 GetBestPath and kaldifst's

@@ -14,6 +14,11 @@
  * and cannot be built here (Eigen, OpenFst, kaldifst, kaldi_native_io are
  * network-fetched): for those functions this oracle is "PARITY UNPINNED" -- a
  * line-by-line restatement cross-checked only by an independent exact Viterbi.
+ * Exception (round 4): the decoder's HashList.  csrc/hash-list.h needs the standard
+ * library only; oracle/ref_hashlist_harness.cc compiles it where it lies
+ * (make -C oracle ref -> oracle/_ref/hashlist_ref) and tests/golden/hashlist_ref.json
+ * holds its recorded answers, which the hl_* code below reproduces
+ * (tests/test_oracle_pins.py).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference/kaldi-hmm-gmm/csrc/).
@@ -217,6 +222,7 @@ void orc_hl_put(void *h, int32_t key, int64_t val);
 int orc_hl_insert(void *h, int32_t key, int64_t val);
 int64_t orc_hl_list(void *h, int32_t *keys, int64_t *vals, int64_t cap);
 int64_t orc_hl_clear_reinsert(void *h, int64_t new_size, int32_t shift);
+void orc_hl_drop(void *h);
 
 /* bench.py's cpu_baseline, variant B: `num_threads` POSIX threads run orc_align_utterance +
  * orc_acc_stats_ali per utterance (private accumulators) over utterances [first_utt, first_utt + n_utt) of a set in

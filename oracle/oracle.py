@@ -80,6 +80,7 @@ def _open(path):
     l.orc_hl_list.restype = C.c_int64
     l.orc_hl_clear_reinsert.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     l.orc_hl_clear_reinsert.restype = C.c_int64
+    l.orc_hl_drop.argtypes = [C.c_void_p]
     return l
 
 
@@ -511,6 +512,9 @@ class OHashList:
 
     def clear_reinsert(self, new_size, shift=1):
         return int(lib().orc_hl_clear_reinsert(self.h, int(new_size), int(shift)))
+
+    def drop(self):
+        lib().orc_hl_drop(self.h)
 
     def close(self):
         if self.h:

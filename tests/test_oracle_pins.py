@@ -4,6 +4,8 @@ inputs; the same formulas are re-evaluated here in numpy float64 and the oracle 
 reference's own tolerances (file:line cited per test)."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -210,3 +212,102 @@ def test_hash_list_insert_keeps_the_first_value_and_list_is_bucket_ordered():
     assert h.items() == [(3, 30), (13, 130), (7, 70), (5, 50)]          # 13 % 10 == 3: behind key 3, ahead of 7
     assert h.find(23) is None and h.find(4) is None
     h.close()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hl_replay(script, backend):
+    """Run a harness script (oracle/ref_hashlist_harness.cc's protocol, with the golden file's packed commands) -> answers in the
+    golden file's packed form.  backend: an object with set_size / insert / put / find / items / drop / clear_reinsert."""
+    import hashlib
+    ans = []
+    bits = []
+
+    def flush():
+        if bits:
+            ans.append("I= " + "".join(bits))
+            bits.clear()
+    for line in script:
+        a = line.split()
+        if a[0] == "I":
+            bits.append("1" if backend.insert(int(a[1]), int(a[2])) else "0")
+            continue
+        if a[0] == "I*":
+            for k in a[2:]:
+                bits.append("1" if backend.insert(int(k), int(a[1])) else "0")
+            continue
+        if a[0] == "S":                      # (commands without an answer do not end a run of Insert answers)
+            backend.set_size(int(a[1]))
+        elif a[0] == "P":
+            backend.put(int(a[1]), int(a[2]))
+        elif a[0] == "D":
+            backend.drop()
+        elif a[0] == "F":
+            flush()
+            v = backend.find(int(a[1]))
+            ans.append("F none" if v is None else f"F {v}")
+        elif a[0] == "L":
+            flush()
+            txt = "L" + "".join(f" {k}:{v}" for k, v in backend.items())
+            ans.append("L# %d %s" % (txt.count(":"), hashlib.sha1(txt.encode()).hexdigest()[:16]) if txt.count(":") > 12 else txt)
+        elif a[0] == "R":
+            flush()
+            ans.append(f"R {backend.clear_reinsert(int(a[1]), int(a[2]))}")
+        else:
+            raise AssertionError(line)
+    flush()
+    return ans
+
+
+def test_hash_list_against_answers_recorded_from_the_reference_itself():
+    """tests/golden/hashlist_ref.json holds what the REFERENCE's own HashList answered (csrc/hash-list.h compiled as it lies,
+    oracle/ref_hashlist_harness.cc; recorded by tests/golden/make_hashlist_golden.py): random Insert / find-or-insert / Find / list
+    / clear-and-reinsert mixes, and the decoder's own pattern on state sets larger than the hash size (shared buckets: the list
+    order is NOT the insertion order).  The oracle's restatement -- the decoder's own code -- must give the same answers."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "hashlist_ref.json")) as fh:
+        gold = json.load(fh)
+    assert len(gold["cases"]) >= 16
+    shared = 0
+    for case in gold["cases"]:
+        h = orc.OHashList()
+        got = _hl_replay(case["script"], h)
+        h.close()
+        assert got == case["answers"]
+        shared += sum(1 for x in case["answers"] if x.startswith("L# "))
+    assert shared > 100
+
+
+def test_hash_list_against_the_reference_binary_when_it_is_here():
+    """Where oracle/_ref/hashlist_ref exists (this container: `make -C oracle ref` compiles the reference's header from
+    /root/reference), a fresh random script goes through the reference binary and the oracle side by side."""
+    import subprocess
+    binary = os.path.join(ROOT, "oracle", "_ref", "hashlist_ref")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/hashlist_ref not built (no /root/reference here)")
+    rng = np.random.default_rng(77)
+    script = ["S 64"]
+    for f in range(60):
+        script += ["D", f"S {64 + 8 * f}"] + [f"I {int(k)} {f}" for k in rng.integers(0, 3000, size=int(rng.integers(5, 400)))] + ["L"]
+        script += [f"F {int(k)}" for k in rng.integers(0, 3000, size=5)]
+    r = subprocess.run([binary], input="\n".join(script) + "\n", capture_output=True, text=True, check=True)
+    want = r.stdout.splitlines()
+
+    h = orc.OHashList()
+    got = []
+    for line in script:
+        a = line.split()
+        if a[0] == "S":
+            h.set_size(int(a[1]))
+        elif a[0] == "D":
+            h.drop()
+        elif a[0] == "I":
+            got.append("I 1" if h.insert(int(a[1]), int(a[2])) else "I 0")
+        elif a[0] == "F":
+            v = h.find(int(a[1]))
+            got.append("F none" if v is None else f"F {v}")
+        elif a[0] == "L":
+            got.append("L" + "".join(f" {k}:{v}" for k, v in h.items()))
+    h.close()
+    assert got == want
