@@ -1386,13 +1386,19 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     for (size_t k = 0; k < u->pdfs.size(); ++k) {
       const int p = u->pdfs[k];
       const int nt = m->pdf_tile_off[p + 1] - m->pdf_tile_off[p];
-      if (nt > 0xffff) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: a pdf of more than 2M Gaussians");
+      if (nt > (int)K1S_NT_MASK) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: a pdf of more than 512k Gaussians");
       const uint32_t need = reachable_only ? (uint32_t)std::min<int64_t>(255, (int64_t)u->pdf_first[k] / 32) : 0u;
       // last needed tile: 255 = no limit (also a pdf no accepting path reads, last = -1: tile 0 ... nothing past it is computed
       // only when last >= 0; a never-needed pdf keeps last tile 0 so that the kernel's [first, last] range is at most one tile)
-      uint32_t last = 255u;
-      if (band) { const int32_t pl = u->pdf_last[k]; last = pl < 0 ? 0u : (uint32_t)std::min<int32_t>(255, pl / 32); }
-      units[k] = K1sUnit{m->pdf_tile_off[p], (uint32_t)nt | (need << 16) | (last << 24)};
+      uint32_t last = 255u, halves = 0u;
+      if (band) {
+        const int32_t pl = u->pdf_last[k];
+        last = pl < 0 ? 0u : (uint32_t)std::min<int32_t>(255, pl / 32);
+        // which half of its first / last tile the band starts / ends in (the kernel's half-tile shift)
+        if (need < 255u && (u->pdf_first[k] % 32) >= 16) halves |= 0x4000u;
+        if (pl < 0 || last == 255u || (pl % 32) >= 16) halves |= 0x8000u;
+      }
+      units[k] = K1sUnit{m->pdf_tile_off[p], (uint32_t)nt | halves | (need << 16) | (last << 24)};
     }
     rc = dev_upload(ctx, &u->sunits_d, units);
     if (rc) return rc;

@@ -923,11 +923,12 @@ def test_band_loglikes_fill_only_dead_cells_and_align_identically(ctx, opt, beam
     res_full = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1, max_active=max_active)
     poff, pdfs = us.pdf_lists()
     last_dev = us.pdf_last_frames()
+    first_dev = us.pdf_first_frames()
     POISON = np.float32(12345.0)
     us.upload_loglikes([np.full_like(f, POISON) for f in full])
     us.loglikes(dm, band=True)
     part = us.download_loglikes()
-    filled = total = 0
+    filled = total = shifted = 0
     for u in range(us.n_utt):
         pl = pdfs[poff[u]: poff[u + 1]]
         T = int(ut.frame_off[u + 1] - ut.frame_off[u])
@@ -935,8 +936,20 @@ def test_band_loglikes_fill_only_dead_cells_and_align_identically(ctx, opt, beam
         last = _last_frames(ut.graphs, u, m.id2pdf, pl, T)
         assert [last[int(p)] for p in pl] == last_dev[poff[u]: poff[u + 1]].tolist()
         for j, p in enumerate(pl):
-            t0 = 32 * (min(first[int(p)], 10**6) // 32)
-            t1 = min(32 * (max(last[int(p)], 0) // 32 + 1), full[u].shape[1])
+            fp, lp = min(first[int(p)], 10**6), max(last[int(p)], 0)
+            fd = int(first_dev[poff[u] + j])                 # the library's own first readable frame (never later than the graph's)
+            assert fd <= fp
+            fp = fd
+            t0 = 32 * (fp // 32)
+            t1 = min(32 * (lp // 32 + 1), full[u].shape[1])
+            if last[int(p)] >= 0 and fp % 32 >= 16 and lp % 32 < 16 and lp // 32 > fp // 32 and (part[u][j, t0:t0 + 16] == POISON).all():
+                # half-tile shift: the band starts in the second half of its first tile and ends in the first half of its last one --
+                # its tiles start 16 frames late, one fewer of them; the half tile in front stays untouched.  (A band that crosses
+                # the 480-frame chunks of a long utterance keeps the aligned tiles.)
+                assert T <= 480
+                t0, t1 = t0 + 16, 32 * (lp // 32) + 16
+                shifted += 1
+            assert fp >= t0 and (last[int(p)] < 0 or lp < t1)
             assert np.array_equal(part[u][j, t0:t1], full[u][j, t0:t1]), (u, j)
             tail = part[u][j, max(t1, t0):]
             if tail.size:
@@ -945,6 +958,7 @@ def test_band_loglikes_fill_only_dead_cells_and_align_identically(ctx, opt, beam
                 filled += tail.size
             total += full[u].shape[1]
     assert filled > 0.05 * total, (filled, total)
+    assert shifted > 20, "no band took the half-tile shift"
     res = us.align(tm, beam=beam, retry_beam=retry, acoustic_scale=0.1, max_active=max_active)
     assert np.array_equal(res["ali"], res_full["ali"]) and np.array_equal(res["status"] & 3, res_full["status"] & 3)
     np.testing.assert_array_equal(res["like"], res_full["like"])
