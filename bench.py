@@ -436,9 +436,9 @@ def main():
             ft = np.minimum(first // 32, 255)
             end = np.minimum(32 * (np.maximum(lt, ft - 1) + 1), Tu)      # cells up to here are computed (or skipped at the front)
             skipped_cells += float((Tu - end).sum())
-            # half-tile shift: a band that starts in the second half of its first tile and ends in the first half of its last one
-            # (both known, at least two tiles) is covered by one 32-frame tile fewer
-            shifted = (last >= 0) & (ft < 255) & (lt < 254) & (first % 32 >= 16) & (last % 32 < 16) & (lt - ft >= 1)
+            # shifted tiles: a band that ends earlier inside its tile than it starts (both known, at least two tiles) is covered by
+            # one 32-frame tile fewer
+            shifted = (last >= 0) & (ft < 255) & (lt < 254) & (last % 32 < first % 32) & (lt - ft >= 1)
             skipped_cells += 32.0 * float(np.count_nonzero(shifted))
     k1_exec_frac = 1.0 - skipped_cells / max(float((T * npdf).sum()), 1.0)
     args.band_effective = band
@@ -689,7 +689,7 @@ def main():
                                                     "peak the fp32 kernels are bound by: > 1 means past that roofline"},
                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                         "executed_cell_fraction": k1_exec_frac,
-                        "k1_cells": "band: per pdf from its first readable to its last useful 32-frame tile, the tiles 16 frames late where that saves one (khg_loglikes_band)" if band else
+                        "k1_cells": "band: per pdf from its first readable to its last useful 32-frame tile, the tiles starting at the band's first frame where that saves one (khg_loglikes_band)" if band else
                                     ("all" if args.full_loglikes else "from each pdf's first readable tile (khg_loglikes_reachable)"),
                         "note": "achieved/frac: 16-bit FLOPs of the dense T x P_u contract (%d partial products per fp32 product) / kernel time "
                                 "/ the 2.5 PFLOP/s dense fp16 = bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame "

@@ -1380,31 +1380,35 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
   const int pack = (KS != 5 || (ctx->opt[KHG_OPT_K1_DBG] & 16)) ? 1 : maxG <= 8 ? 4 : maxG <= 16 ? 2 : 1;
   const bool band = reach == 2 && pack == 1 && u->pdf_last.size() == u->pdfs.size();     // (the packed kernel keeps the front-only form)
   // one unit per (utterance, listed pdf): first W tile, number of W tiles, first (and, BAND form, last) needed 32-frame tile
-  if (u->sunits_pto != m->pdf_tile_off || u->sunits_reach != (band ? 2 : (int)reachable_only)) {
+  // (KHG_K1B_DBG bits 32 / 64, A/B only: no shifted tiles / only the 16-frame shift)
+  const int shift_mode = (ctx->opt[KHG_OPT_K1_DBG] & 32) ? 0 : (ctx->opt[KHG_OPT_K1_DBG] & 64) ? 1 : 2;
+  const int units_key = (band ? 2 : (int)reachable_only) + 4 * shift_mode;
+  if (u->sunits_pto != m->pdf_tile_off || u->sunits_reach != units_key) {
     DEVFREE(u->sunits_d);
     std::vector<K1sUnit> units(u->pdfs.size());
     for (size_t k = 0; k < u->pdfs.size(); ++k) {
       const int p = u->pdfs[k];
       const int nt = m->pdf_tile_off[p + 1] - m->pdf_tile_off[p];
-      if (nt > (int)K1S_NT_MASK) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: a pdf of more than 512k Gaussians");
+      if (nt > (int)K1S_NT_MASK) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: a pdf of more than 65 504 Gaussians");
       const uint32_t need = reachable_only ? (uint32_t)std::min<int64_t>(255, (int64_t)u->pdf_first[k] / 32) : 0u;
       // last needed tile: 255 = no limit (also a pdf no accepting path reads, last = -1: tile 0 ... nothing past it is computed
       // only when last >= 0; a never-needed pdf keeps last tile 0 so that the kernel's [first, last] range is at most one tile)
-      uint32_t last = 255u, halves = 0u;
+      uint32_t last = 255u, shift = 0u;
       if (band) {
         const int32_t pl = u->pdf_last[k];
         last = pl < 0 ? 0u : (uint32_t)std::min<int32_t>(255, pl / 32);
-        // which half of its first / last tile the band starts / ends in (the kernel's half-tile shift)
-        if (need < 255u && (u->pdf_first[k] % 32) >= 16) halves |= 0x4000u;
-        if (pl < 0 || last == 255u || (pl % 32) >= 16) halves |= 0x8000u;
+        // the band ends earlier inside its tile than it starts: tiles that start at its first frame cover it with one tile fewer
+        if (pl >= 0 && need < 255u && last < 255u && last > need && (pl % 32) < (u->pdf_first[k] % 32)) shift = (uint32_t)(u->pdf_first[k] % 32);
+        if (shift_mode == 0) shift = 0u;
+        else if (shift_mode == 1) shift = (shift >= 16u && (pl % 32) < 16) ? 16u : 0u;
       }
-      units[k] = K1sUnit{m->pdf_tile_off[p], (uint32_t)nt | halves | (need << 16) | (last << 24)};
+      units[k] = K1sUnit{m->pdf_tile_off[p], (uint32_t)nt | (shift << 11) | (need << 16) | (last << 24)};
     }
     rc = dev_upload(ctx, &u->sunits_d, units);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     u->sunits_pto = m->pdf_tile_off;
-    u->sunits_reach = band ? 2 : (int)reachable_only;
+    u->sunits_reach = units_key;
   }
   // BAND form: the per-pdf upper bounds the skipped tiles are filled with, indexed by a pdf's first W tile; per parameter version
   if (band && !m->ubound_valid) {
