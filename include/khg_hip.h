@@ -91,7 +91,8 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_K1_NF 2          /* fp32 utterance-major K1: 16-frame tiles per wave at D <= 40 (0 = 6, or 5)     [KHG_K1_NF] */
 #define KHG_OPT_K1P_TS 3         /* fp32 pdf-major K1: tiles per workgroup slice (default 1024)                  [KHG_K1P_TS] */
 #define KHG_OPT_K1_INTERLEAVE 4  /* fp32 utterance-major K1: frame tiles dealt round-robin (-1 auto, 0, 1)        [KHG_K1_INTERLEAVE] */
-#define KHG_OPT_K1_DBG 5         /* experiment bit mask of the tile-major split forms (results may be WRONG)      [KHG_K1B_DBG] */
+#define KHG_OPT_K1_DBG 5         /* experiment bit mask (bits 1-8: the tile-major split forms, results may be WRONG; 16: no packing of
+                                    small pdfs; 32 / 64: K1s band form without shifted tiles / 16-frame shift only)  [KHG_K1B_DBG] */
 #define KHG_OPT_K2_INORDER 6     /* 1: K2 workgroups in utterance order instead of longest first                  [KHG_K2_INORDER] */
 #define KHG_OPT_K2_KS 7          /* states per thread on K2's register-resident path: 0 auto, 2, 4; 3 = the general three-slot kernel also where the two-slot one applies [KHG_K2_KS] */
 #define KHG_OPT_K2_SERIAL 8      /* 1: the one-lane order-faithful decoder also where the wave form applies;
