@@ -170,8 +170,10 @@ int khg_loglikes_reachable(khg_ctx *ctx, const khg_model *m, khg_utts *u);
  * of khg_align sees such tokens at costs no higher than the reference decoder would -- its beam certificate stays sound and the
  * best path is untouched.  An utterance whose certificate fails is recomputed without the band by khg_align itself before the
  * order-faithful decoder reads it (the model handle must stay alive, unchanged, until that khg_align returns): alignments are
- * identical to khg_loglikes + khg_align at any beam.  Worth it when the beam is wide (few certificates fail): ~13 % fewer cells at
- * the benchmark's shape.  Default K1 form only (f16x2s, pdfs of more than 16 Gaussians); anything else: khg_loglikes_reachable. */
+ * identical to khg_loglikes + khg_align at any beam.  Worth it when the beam is wide (few certificates fail): ~21 % fewer cells at
+ * the benchmark's shape.  Cells of a pdf BEFORE its first readable frame are unspecified (as with khg_loglikes_reachable, here to
+ * the frame: a band's 32-frame tiles may start at that frame instead of on the 32-frame grid).  Default K1 form only (f16x2s, pdfs
+ * of more than 16 Gaussians); anything else: khg_loglikes_reachable. */
 int khg_loglikes_band(khg_ctx *ctx, const khg_model *m, khg_utts *u);
 /* per listed pdf: the last frame at which an arc carrying it can still lead to a final state by the utterance's end (-1: never;
  * INT32_MAX for sets without graphs) */
