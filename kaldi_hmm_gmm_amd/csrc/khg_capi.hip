@@ -1765,8 +1765,15 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     if (rc) return rc;
     {
       KernelTimer kt(ctx, "k1_band_repair", side);
-      if (u->band_ks == 5) hipLaunchKernelGGL((k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), u->band_lds, side, ra);
-      else hipLaunchKernelGGL((k1s_loglikes<10>), dim3(u->n_schunks), dim3(512), u->band_lds, side, ra);
+      const size_t lds_r = u->band_lds + 4 * 513;          // + the list of flagged chunks
+      const unsigned gr = (unsigned)std::min<int64_t>(256, ((int64_t)u->n_schunks + 511) / 512);
+      if (u->band_ks == 5) {
+        HIPCHK(hipFuncSetAttribute((const void*)k1s_repair<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+        hipLaunchKernelGGL((k1s_repair<5>), dim3(gr), dim3(512), lds_r, side, ra, (int)u->n_schunks);
+      } else {
+        HIPCHK(hipFuncSetAttribute((const void*)k1s_repair<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+        hipLaunchKernelGGL((k1s_repair<10>), dim3(gr), dim3(512), lds_r, side, ra, (int)u->n_schunks);
+      }
     }
     HIPCHK(hipGetLastError());
     rc = bm->wimgs_sync.after_read(side);

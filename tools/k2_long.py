@@ -16,7 +16,9 @@ tm = DeviceTransitions(ctx, m.id2pdf)
 il = np.arange(m.num_tids + 1, dtype=np.int32)
 cost = orc.add_transition_probs(il, np.zeros(m.num_tids + 1, np.float32), m.log_probs, m.non_self_loop_log_probs, m.id2state, m.is_self_loop, 1.0, 0.1)
 tm.set_trans_cost(cost)
-for lo, hi in ((10, 40), (40, 100), (100, 200), (200, 330), (340, 600)):
+import os
+RANGES = eval(os.environ.get('K2_LONG_RANGES', '((10, 40), (40, 100), (100, 200), (200, 330), (340, 600))'))
+for lo, hi in RANGES:
     U = int(MF * 1e6 / (12.0 * (lo + hi) / 2))
     ut = synth.make_utts(m, U, seed=5, min_phones=lo, max_phones=hi, feats=False)
     feats = synth.sample_feats_torch(m, ut.frame_pdf, 7, torch.device("cuda", 0))
