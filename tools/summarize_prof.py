@@ -49,8 +49,8 @@ def counters(sub):
 
 
 def mean(v):
-    """Average over the MAIN launches of a kernel: a kernel that is also launched as a small side job (K1's band repair launch: same
-    kernel, a few flagged utterances) would otherwise halve every per-launch figure.  Dispatches under a tenth of the largest are left out."""
+    """Average over the MAIN launches of a kernel: a kernel that is also launched as a small side job (a warm-up on a few frames, a
+    per-model pass) would otherwise pull every per-launch figure down.  Dispatches under a tenth of the largest are left out."""
     v = [x for x in v if x >= 0.1 * max(v)] if v else v
     return sum(v) / len(v) if v else 0.0
 
@@ -139,8 +139,7 @@ lines = [f"# Round {TAG[1:]} rocprofv3 summaries (MI355X, gfx950)", "",
          f"## Kernel trace ({TAG}_kernel_stats.csv)", "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
 for r in stats[:10]:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {r['Percentage']} |")
-lines += ["", "Kernels that also run as a small side launch (K1's band repair launch is the same `k1s_loglikes` kernel on the flagged utterances only): "
-          "average over the main launches, from the kernel trace:", ""]
+lines += ["", "Kernels that also run as a much smaller side launch (warm-up calls, per-model passes): average over the main launches, from the kernel trace:", ""]
 for k, v in durs.items():
     main = [x for x in v if x >= 0.1 * max(v)]
     if len(main) != len(v) and any(o in k for o in OURS):
