@@ -160,9 +160,9 @@ int khg_loglikes(khg_ctx *ctx, const khg_model *m, khg_utts *u);
 /* Same, restricted to the (frame, pdf) cells the decoder can read: DecodableAmDiagGmmScaled only
  * evaluates LogLikelihood(frame, tid) for tokens that exist (csrc/faster-decoder.cc:208), and no token
  * can sit in a state before as many frames as the fewest emitting arcs from the start state lead to
- * it.  Cells of a pdf in 16-frame tiles that end before that are left untouched (unspecified
- * contents); alignments are identical to khg_loglikes + khg_align.  Sets without graphs: same as
- * khg_loglikes. */
+ * it.  Cells of a pdf before its first readable frame are unspecified (whole tiles in front of it are
+ * left untouched, and a pdf's tiles may start at that very frame); alignments are identical to
+ * khg_loglikes + khg_align.  Sets without graphs: same as khg_loglikes. */
 int khg_loglikes_reachable(khg_ctx *ctx, const khg_model *m, khg_utts *u);
 /* The BAND form: additionally leaves out what only tokens that can no longer reach a final state read -- a (pdf, 32-frame tile)
  * past the last frame at which an arc carrying the pdf still leads to a final state by the utterance's end (fewest emitting arcs

@@ -1382,10 +1382,19 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
   // one unit per (utterance, listed pdf): first W tile, number of W tiles, first (and, BAND form, last) needed 32-frame tile
   // (KHG_K1B_DBG bits 32 / 64, A/B only: no shifted tiles / only the 16-frame shift)
   const int shift_mode = (ctx->opt[KHG_OPT_K1_DBG] & 32) ? 0 : (ctx->opt[KHG_OPT_K1_DBG] & 64) ? 1 : 2;
+  // khg_loglikes_reachable (no band): a pdf's tiles run to the utterance's end, which is a band whose last frame is T - 1 -- the same
+  // shifted tiles save the same tile (every second pdf); the kernel takes its band path, the fill only meets padding frames
+  const bool tail_shift = !band && reachable_only && pack == 1 && shift_mode != 0 && u->pdf_first.size() == u->pdfs.size();
   const int units_key = (band ? 2 : (int)reachable_only) + 4 * shift_mode;
   if (u->sunits_pto != m->pdf_tile_off || u->sunits_reach != units_key) {
     DEVFREE(u->sunits_d);
     std::vector<K1sUnit> units(u->pdfs.size());
+    std::vector<int32_t> unit_T;                     // tail_shift: the utterance length of every unit
+    if (tail_shift) {
+      unit_T.resize(u->pdfs.size());
+      for (int i = 0; i < u->n_utt; ++i)
+        for (int64_t k = u->pdf_off[(size_t)i]; k < u->pdf_off[(size_t)i + 1]; ++k) unit_T[(size_t)k] = (int32_t)std::min<int64_t>(INT32_MAX, u->frame_off[(size_t)i + 1] - u->frame_off[(size_t)i]);
+    }
     for (size_t k = 0; k < u->pdfs.size(); ++k) {
       const int p = u->pdfs[k];
       const int nt = m->pdf_tile_off[p + 1] - m->pdf_tile_off[p];
@@ -1394,8 +1403,8 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
       // last needed tile: 255 = no limit (also a pdf no accepting path reads, last = -1: tile 0 ... nothing past it is computed
       // only when last >= 0; a never-needed pdf keeps last tile 0 so that the kernel's [first, last] range is at most one tile)
       uint32_t last = 255u, shift = 0u;
-      if (band) {
-        const int32_t pl = u->pdf_last[k];
+      if (band || tail_shift) {
+        const int32_t pl = band ? u->pdf_last[k] : unit_T[k] - 1;
         last = pl < 0 ? 0u : (uint32_t)std::min<int32_t>(255, pl / 32);
         // the band ends earlier inside its tile than it starts: tiles that start at its first frame cover it with one tile fewer
         if (pl >= 0 && need < 255u && last < 255u && last > need && (pl % 32) < (u->pdf_first[k] % 32)) shift = (uint32_t)(u->pdf_first[k] % 32);
@@ -1411,7 +1420,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     u->sunits_reach = units_key;
   }
   // BAND form: the per-pdf upper bounds the skipped tiles are filled with, indexed by a pdf's first W tile; per parameter version
-  if (band && !m->ubound_valid) {
+  if ((band || tail_shift) && !m->ubound_valid) {
     if (!m->ubound_d || m->ubound_tiles < m->ntiles) {
       DEVFREE(m->ubound_d);
       rc = dev_alloc(&m->ubound_d, (size_t)m->ntiles);
@@ -1429,7 +1438,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
   a.c1 = std::ldexp(1.44269504088896340736f, -S);
   a.inv_scale = std::ldexp(1.0f, -S);
   a.mfloor = -3.0e38f / std::max(1.0f, a.c1);
-  a.ubound = band ? m->ubound_d : nullptr; a.repair_status = nullptr; a.repair_bit = 0;
+  a.ubound = (band || tail_shift) ? m->ubound_d : nullptr; a.repair_status = nullptr; a.repair_bit = 0;
   u->ll_mode = band ? 2 : (reachable_only ? 1 : 0);
   if (u->n_schunks > 0) {
     rc = m->wimgs_sync.before_read(ctx->stream);
