@@ -1,0 +1,307 @@
+// kaldi_hmm_gmm_amd/csrc/khg_ctx_model.hip -- C-ABI (include/khg_hip.h): errors, the per-device context and its options, the
+// acoustic-model handle (row-major parameters + the fp32 K1 tile image, packed on the device) and the transition table.  gfx950 only.
+#include "khg_internal.hpp"
+#include "khg_k1_loglikes.hip.inc"     // the tile geometry (khg_row_floats / khg_tile_floats) k0_pack_tiles shares with K1
+
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+extern "C" const char* khg_last_error(void) { return g_err.c_str(); }
+int khg_set_error(int code, const std::string& msg) { g_err = msg; return code; }  // shared with khg_host.cpp
+extern "C" int khg_version(void) { return 100; }
+
+static void ctx_defaults_from_env(khg_ctx* c);
+extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
+  if (!out) return khg_set_error(KHG_E_ARG, "khg_ctx_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return khg_set_error(KHG_E_HIP, "khg_ctx_create: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return khg_set_error(KHG_E_ARG, "khg_ctx_create: bad device index");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return khg_set_error(KHG_E_UNSUPPORTED, std::string("khg_ctx_create: built for gfx950, device is ") + prop.gcnArchName);
+  khg_ctx* c = new khg_ctx();
+  c->device = device;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  for (auto& s : c->sides) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  ctx_defaults_from_env(c);
+  int rc = dev_alloc(&c->err_flag_d, 1);
+  if (!rc) rc = dev_alloc(&c->dump_d, 256);
+  if (rc) { delete c; return rc; }
+  HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
+  *out = c;
+  return KHG_OK;
+}
+extern "C" int khg_ctx_destroy(khg_ctx* c) {
+  if (!c) return KHG_OK;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->sides) (void)hipStreamSynchronize(s);
+  DEVFREE(c->err_flag_d); DEVFREE(c->dump_d);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  for (auto& s : c->sides) (void)hipStreamDestroy(s);
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+  if (c->ev_k3) (void)hipEventDestroy(c->ev_k3);
+  if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
+  delete c;
+  return KHG_OK;
+}
+extern "C" int khg_ctx_set_timing(khg_ctx* c, int on) {
+  if (!c) return khg_set_error(KHG_E_ARG, "ctx is NULL");
+  c->timing = on != 0;
+  return KHG_OK;
+}
+// drains the recorded (kernel name, milliseconds) pairs; names are '\n'-separated
+extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, float* ms, int32_t cap, int32_t* n_out) {
+  if (!c || !n_out) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& s : c->sides) HIPCHK(hipStreamSynchronize(s));
+  int n = 0; std::string all;
+  for (auto& t : c->timings) {
+    float v = 0.0f;
+    (void)hipEventElapsedTime(&v, t.e0, t.e1);
+    if (n < cap && ms) ms[n] = v;
+    all += t.name; all += '\n';
+    (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1);
+    ++n;
+  }
+  c->timings.clear();
+  if (names && names_cap > 0) { size_t k = std::min<size_t>(all.size(), (size_t)names_cap - 1); memcpy(names, all.data(), k); names[k] = 0; }
+  *n_out = n;
+  return KHG_OK;
+}
+// valid range of every option (inclusive)
+static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 2}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
+extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
+  if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
+  if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
+    return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: option " + std::to_string(opt) + " takes values " + std::to_string(k_opt_range[opt].lo) + " .. " + std::to_string(k_opt_range[opt].hi));
+  c->opt[opt] = value;
+  return KHG_OK;
+}
+extern "C" int khg_ctx_get_option(const khg_ctx* c, int opt, int* value) {
+  if (!c || !value || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_get_option: bad arguments");
+  *value = c->opt[opt];
+  return KHG_OK;
+}
+extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) { return khg_ctx_set_option(c, KHG_OPT_K1_FORM, form); }
+// Defaults from the environment, read ONCE per context (A/B runs of an unmodified caller): NAME=value, value an integer or one of the words
+// listed.  Everything else goes through khg_ctx_set_option.
+static void ctx_defaults_from_env(khg_ctx* c) {
+  static const struct { const char* name; int opt; const char* words; } tab[] = {
+    {"KHG_K1", KHG_OPT_K1_FORM, "auto=0,bf16x3=1,pdf=2,fp32=2,utt=3,f16x2=4,f16x2s=5"},
+    {"KHG_K1_ORDER", KHG_OPT_K1_ORDER, "desc=0,none=1,asc=2,tiles=3"},
+    {"KHG_K1_NF", KHG_OPT_K1_NF, ""}, {"KHG_K1P_TS", KHG_OPT_K1P_TS, ""}, {"KHG_K1_INTERLEAVE", KHG_OPT_K1_INTERLEAVE, ""},
+    {"KHG_K1B_DBG", KHG_OPT_K1_DBG, ""}, {"KHG_K2_INORDER", KHG_OPT_K2_INORDER, ""}, {"KHG_K2_KS", KHG_OPT_K2_KS, ""},
+    {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},
+    {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1,count=2"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
+    {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1,f16=2"},
+    {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}, {"KHG_K3_PHASEA", KHG_OPT_K3_PHASE_A, "auto=0,f16=0,f32=1"}};
+  c->opt[KHG_OPT_K1_INTERLEAVE] = -1;
+  c->opt[KHG_OPT_K1P_TS] = 1024;
+  c->opt[KHG_OPT_K3_PHASE_B] = 2;        // both phases of K3's wave form on the fp16 matrix cores where they apply (else the fp64 pipe)
+  for (const auto& t : tab) {
+    const char* e = getenv(t.name);
+    if (!e || !*e) continue;
+    int v = atoi(e);
+    bool word = false;
+    for (const char* w = t.words; *w;) {                 // "word=value,word=value"
+      const char* eq = strchr(w, '=');
+      const size_t n = (size_t)(eq - w);
+      if (strlen(e) == n && strncmp(e, w, n) == 0) { v = atoi(eq + 1); word = true; break; }
+      const char* comma = strchr(eq, ',');
+      if (!comma) break;
+      w = comma + 1;
+    }
+    if (!word && *t.words && !(e[0] >= '0' && e[0] <= '9') && e[0] != '-') continue;      // an unknown word: ignored
+    if (v >= k_opt_range[t.opt].lo && v <= k_opt_range[t.opt].hi) c->opt[t.opt] = v;
+  }
+}
+extern "C" int khg_ctx_sync(khg_ctx* c) {
+  if (!c) return khg_set_error(KHG_E_ARG, "ctx is NULL");
+  return check_err_flag(c, "khg_ctx_sync");   // synchronises the stream, then reports deferred kernel errors
+}
+// read-and-clear the device error word; maps bits to the reference's exceptions
+int check_err_flag(khg_ctx* c, const char* where) {
+  int32_t f = 0;
+  for (auto& s : c->sides) HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemcpyAsync(&f, c->err_flag_d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (f) {
+    HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
+    if (f & 1) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": Invalid answer (overflow or invalid variances/features?)");
+    if (f & 2) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": internal queue overflow in the faithful decoder");
+    if (f & 8) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": internal error: K3 work items exceed their bound");
+    return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": pdf-id out of range (graph/model mismatch)");
+  }
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: pack the K1 tile image from the row-major parameters (one workgroup per W tile).
+// planes q = 0..3 of [32][ROW]: q=0/1: means_invvars at even/odd d, q=2/3: -0.5*inv_vars (exact
+// scaling) at even/odd d, element s of a row <-> d = 2s + (q&1); then gconst[32].  Padding rows:
+// W = 0, gconst = -inf (they contribute exp2(-inf) = 0 to the log-sum-exp).  Also writes the
+// row-major -0.5*inv_vars copy K3 uses.
+template <int KQ>
+__global__ __launch_bounds__(256) void k0_pack_tiles(const float* __restrict__ gconsts, const float* __restrict__ miv,
+                                                      const float* __restrict__ iv, const int32_t* __restrict__ gauss_off,
+                                                      const int32_t* __restrict__ pdf_tile_off, const int32_t* __restrict__ tile_pdf,
+                                                      int D, float* __restrict__ wimg, float* __restrict__ nhiv) {
+  constexpr int ROW = khg_row_floats(KQ), TILE = khg_tile_floats(KQ);
+  const int t = blockIdx.x, p = tile_pdf[t];
+  const int g_first = gauss_off[p] + 32 * (t - pdf_tile_off[p]);
+  const int nrow = min(32, gauss_off[p + 1] - g_first);
+  float* img = wimg + (size_t)t * TILE;
+  for (int i = threadIdx.x; i < TILE; i += 256) {
+    float v = 0.0f;
+    if (i < 4 * 32 * ROW) {
+      const int q = i / (32 * ROW), r = (i / ROW) & 31, s = i % ROW;
+      const int d = 2 * s + (q & 1);
+      if (r < nrow && d < D) {
+        const size_t src = (size_t)(g_first + r) * D + d;
+        v = (q & 2) ? -0.5f * iv[src] : miv[src];
+      }
+    } else if (i < 4 * 32 * ROW + 32) {
+      const int r = i - 4 * 32 * ROW;
+      v = r < nrow ? gconsts[g_first + r] : -INFINITY;
+    }
+    img[i] = v;
+  }
+  for (int i = threadIdx.x; i < nrow * D; i += 256) nhiv[(size_t)g_first * D + i] = -0.5f * iv[(size_t)g_first * D + i];
+}
+
+// -0.5 * inv_vars for K3 when no tile image is packed
+__global__ void k0_nhalf(const float* __restrict__ iv, int64_t n, float* __restrict__ nhiv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) nhiv[i] = -0.5f * iv[i];
+}
+
+// (Re)build everything derived from gauss_off + the row-major parameters in HBM: the tile offsets, the K1
+// tile image and the -0.5*inv_vars copy K3 reads -- packed ON THE DEVICE (k0_pack_tiles), no host-side
+// 113 MB image, no extra copies.  Used by khg_model_create and after the device M-step.
+int model_pack(khg_ctx* ctx, khg_model* m) {
+  const int P = m->P, D = m->D;
+  m->pdf_tile_off.resize((size_t)P + 1);
+  int nt = 0;
+  for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (m->gauss_off[p + 1] - m->gauss_off[p] + 31) / 32; }
+  m->pdf_tile_off[P] = nt;
+  m->ntiles = nt;
+  const int TILE = m->KQ ? khg_tile_floats(m->KQ) : 0;
+  if (!m->pdf_tile_off_d) { int rc = dev_alloc(&m->pdf_tile_off_d, (size_t)P + 1); if (rc) return rc; }
+  if (!m->gauss_off_d) { int rc = dev_alloc(&m->gauss_off_d, (size_t)P + 1); if (rc) return rc; }
+  HIPCHK(hipMemcpyAsync(m->pdf_tile_off_d, m->pdf_tile_off.data(), sizeof(int32_t) * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(m->gauss_off_d, m->gauss_off.data(), sizeof(int32_t) * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (!m->nhiv_d) { int rc = dev_alloc(&m->nhiv_d, (size_t)m->sumG * D); if (rc) return rc; }
+  if (m->KQ == 0) {
+    // any-dimension model (D > 80): no tile images; K3 still reads -0.5 * inv_vars
+    m->KS = 0;
+    m->wimgb_valid = false;
+    m->wimgh_ex.clear(); m->wimgs_key.clear(); m->ubound_valid = false; m->wmax.clear(); m->k3_xb.clear();
+    const int64_t n = m->sumG * D;
+    hipLaunchKernelGGL(k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    return KHG_OK;
+  }
+  if (!m->wimg_d || m->wimg_tiles < nt) {
+    DEVFREE(m->wimg_d);
+    int rc = dev_alloc(&m->wimg_d, (size_t)nt * TILE);
+    if (rc) return rc;
+    m->wimg_tiles = nt;
+  }
+  m->KS = m->KQ == 10 ? 5 : 10;
+  m->wimgb_valid = false;
+  std::vector<int32_t> tile_pdf((size_t)nt);   // tile -> pdf map for the pack kernel
+  for (int p = 0; p < P; ++p)
+    for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
+  DEVFREE(m->tile_pdf_d);
+  m->wimgh_ex.clear();
+  m->wimgs_key.clear(); m->ubound_valid = false;
+  m->wmax.clear(); m->k3_xb.clear();
+  int rc = dev_upload(ctx, &m->tile_pdf_d, tile_pdf);
+  int32_t* tile_pdf_d = m->tile_pdf_d;
+  if (!rc) {
+    KernelTimer kt(ctx, "k0_pack_tiles");
+    if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+    else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+  }
+  if (!rc) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // tile_pdf and the host offset vectors are free after this
+    if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+  }
+  return rc;
+}
+
+extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_t* gauss_off,
+                                const float* gconsts, const float* miv, const float* iv, khg_model** out) {
+  if (!ctx || !out || P <= 0 || D <= 0 || !gauss_off || !gconsts || !miv || !iv)
+    return khg_set_error(KHG_E_ARG, "khg_model_create: bad arguments");
+  if (D > KHG_MAX_DIM) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_create: feature dim > " + std::to_string(KHG_MAX_DIM) + " is not supported (a 64-frame chunk of rows must fit LDS)");
+  if (gauss_off[0] != 0) return khg_set_error(KHG_E_ARG, "khg_model_create: gauss_off[0] != 0");
+  for (int p = 0; p < P; ++p)
+    if (gauss_off[p + 1] <= gauss_off[p]) return khg_set_error(KHG_E_ARG, "khg_model_create: every pdf needs >= 1 Gaussian");
+  khg_model* m = new khg_model();
+  m->ctx = ctx; m->P = P; m->D = D;
+  m->KQ = (D <= 40) ? 10 : (D <= 80) ? 20 : 0;      // 0: no tile image; K1 / K3 run their any-dimension forms (k1w_loglikes, k3_accumulate<0>)
+  m->gauss_off.assign(gauss_off, gauss_off + P + 1);
+  m->sumG = gauss_off[P];
+  // the row-major parameters go up as they are (K3 and the device M-step read them)
+  auto up = [&](float** dst, const float* src, size_t n) -> int {
+    int r = dev_alloc(dst, n);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(*dst, src, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    return KHG_OK;
+  };
+  int rc = up(&m->gconsts_d, gconsts, (size_t)m->sumG);
+  if (!rc) rc = up(&m->miv_d, miv, (size_t)m->sumG * D);
+  if (!rc) rc = up(&m->iv_d, iv, (size_t)m->sumG * D);
+  if (!rc) rc = model_pack(ctx, m);   // ends with a stream sync: the caller's arrays are free after this
+  if (rc) { khg_model_destroy(m); return rc; }
+  *out = m;
+  return KHG_OK;
+}
+extern "C" int khg_model_destroy(khg_model* m) {
+  if (!m) return KHG_OK;
+  m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
+  delete m;
+  return KHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int khg_tm_create(khg_ctx* ctx, int32_t num_tids, const int32_t* id2pdf, khg_tm** out) {
+  if (!ctx || !out || num_tids <= 0 || !id2pdf) return khg_set_error(KHG_E_ARG, "khg_tm_create: bad arguments");
+  khg_tm* t = new khg_tm();
+  t->ctx = ctx; t->num_tids = num_tids;
+  t->id2pdf.assign(id2pdf, id2pdf + num_tids + 1);
+  for (int i = 1; i <= num_tids; ++i) {
+    if (id2pdf[i] < 0) { delete t; return khg_set_error(KHG_E_ARG, "khg_tm_create: negative pdf-id"); }
+    t->max_pdf = std::max(t->max_pdf, id2pdf[i]);
+  }
+  int rc = dev_upload(ctx, &t->id2pdf_d, t->id2pdf);
+  if (!rc) rc = dev_alloc(&t->trans_cost_d, (size_t)num_tids + 1);
+  if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
+  if (rc) { khg_tm_destroy(t); return rc; }
+  *out = t;
+  return KHG_OK;
+}
+extern "C" int khg_tm_set_trans_cost(khg_tm* t, const float* cost) {
+  if (!t) return khg_set_error(KHG_E_ARG, "tm is NULL");
+  if (!cost) { t->has_trans_cost = false; return KHG_OK; }
+  HIPCHK(hipMemcpyAsync(t->trans_cost_d, cost, sizeof(float) * ((size_t)t->num_tids + 1), hipMemcpyHostToDevice, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  t->has_trans_cost = true;
+  return KHG_OK;
+}
+extern "C" int khg_tm_destroy(khg_tm* t) {
+  if (!t) return KHG_OK;
+  DEVFREE(t->id2pdf_d); DEVFREE(t->trans_cost_d);
+  delete t;
+  return KHG_OK;
+}

@@ -13,7 +13,7 @@
 
 #include "../../include/khg_hip.h"
 
-int khg_set_error(int code, const std::string& msg);  // khg_capi.hip
+int khg_set_error(int code, const std::string& msg);  // khg_ctx_model.hip
 
 namespace {
 

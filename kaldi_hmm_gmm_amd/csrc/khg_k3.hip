@@ -1,0 +1,393 @@
+// kaldi_hmm_gmm_amd/csrc/khg_k3.hip -- C-ABI (include/khg_hip.h): the accumulator block and K3, sufficient statistics
+// (khg_acc_stats / khg_acc_stats_reduce): bucketing of frames by pdf, work items, form selection, the launches.  gfx950 only.
+#include "khg_internal.hpp"
+
+#include <hipcub/hipcub.hpp>   // DeviceRadixSort: the stable (pdf, frame) sort of K3's bucketing
+
+#include "khg_k3_accstats.hip.inc"
+
+// ------------------------------------------------------------------------------------------
+// accumulators + K3
+extern "C" int khg_accs_create(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_accs** out) {
+  if (!ctx || !m || !tm || !out) return khg_set_error(KHG_E_ARG, "khg_accs_create: bad arguments");
+  khg_accs* a = new khg_accs();
+  a->ctx = ctx; a->sumG = m->sumG; a->D = m->D; a->num_tids = tm->num_tids;
+  a->n = a->sumG * (1 + 2 * (int64_t)a->D) + a->num_tids + 1 + 8;
+  int rc = dev_alloc(&a->buf_d, (size_t)a->n);
+  if (rc) { delete a; return rc; }
+  a->cap = a->n;
+  *out = a;
+  return khg_accs_zero(ctx, a);
+}
+extern "C" int khg_accs_destroy(khg_accs* a) { if (a) { DEVFREE(a->buf_d); DEVFREE(a->wire_d); delete a; } return KHG_OK; }
+extern "C" int khg_accs_zero(khg_ctx* ctx, khg_accs* a) {
+  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipMemsetAsync(a->buf_d, 0, sizeof(double) * (size_t)a->n, ctx->stream));
+  return KHG_OK;
+}
+extern "C" int khg_accs_size(const khg_accs* a, int64_t* n) { if (!a || !n) return khg_set_error(KHG_E_ARG, "bad arguments"); *n = a->n; return KHG_OK; }
+extern "C" int khg_accs_device_ptr(const khg_accs* a, void** p) { if (!a || !p) return khg_set_error(KHG_E_ARG, "bad arguments"); *p = a->buf_d; return KHG_OK; }
+extern "C" int khg_accs_download(khg_ctx* ctx, const khg_accs* a, double* buf) {
+  if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
+  HIPCHK(hipMemcpyAsync(buf, a->buf_d, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+extern "C" int khg_accs_upload(khg_ctx* ctx, khg_accs* a, const double* buf) {
+  if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  HIPCHK(hipMemcpyAsync(a->buf_d, buf, sizeof(double) * (size_t)a->n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KHG_OK;
+}
+
+// K3, optionally with C1 pipelined behind it: the pdfs are cut into `nparts` ranges; the accumulate kernels of range i + 1 run on
+// the context's stream while the all-reduce of range i's accumulator rows runs on the context's communication stream.
+// K3's phase A on the fp16 matrix cores (khg_k3_accstats.hip.inc, k3_accumulate_wave<NB, true>): the scale exponents come from the
+// MODEL alone -- every rank of a sharded run derives the same ones, so the statistics do not depend on the sharding: per
+// dimension the features are expected inside xb = max_g (|mean| + 8 sigma); x' = x 2^ex peaks in [2^12, 2^13) there (fp16 overflows
+// at ~8 xb), fl(x^2)' in [2^9, 2^10) (same limit), and the largest weight column peaks in [2^14, 2^15) (S).  *use = false (the fp32
+// phase A runs) when the model side of the f16x2s domain fails (khg_k1_f16x2s.hip.inc: the absolute part of the error bound,
+// evaluated at xb, above 4e-6; |S| > 40; the log-sum-exp's 2^28 bound at 16 xb) or when a feature of THIS set overflows fp16.
+static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use) {
+  *use = false;
+  const int D = m->D, K = 80;
+  if (m->KQ != 10 || D > 40) return KHG_OK;
+  std::vector<float> xk;
+  int rc = k1_maxima(ctx, m, u, &xk);          // the set's column maxima (cached) and the model's (wmax, gcmax; cached per version)
+  if (rc) return rc;
+  if (m->k3_xb.empty()) {
+    uint32_t* b_d = nullptr;
+    rc = dev_alloc(&b_d, 64);
+    if (rc) return rc;
+    std::vector<uint32_t> hb(64, 0);
+    hipError_t e = hipMemsetAsync(b_d, 0, 64 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) {
+      const int64_t n = m->sumG;
+      hipLaunchKernelGGL(k3_model_xbound, dim3((int)std::min<int64_t>(2048, (n * D + 255) / 256)), dim3(256), 0, ctx->stream, m->miv_d, m->iv_d, n, D, b_d);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), b_d, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    DEVFREE(b_d);
+    if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
+    m->k3_xb.assign((size_t)D, 0.0f);
+    for (int d = 0; d < D; ++d) memcpy(&m->k3_xb[(size_t)d], &hb[(size_t)d], sizeof(float));
+    m->k3_ex.assign((size_t)K, 0);
+    bool ok = true;
+    for (int d = 0; d < D; ++d) {
+      const float xb = m->k3_xb[(size_t)d];
+      if (!(xb > 0.0f) || !(xb < 1.0e18f)) { ok = false; break; }
+      m->k3_ex[(size_t)2 * d] = 12 - std::ilogb(xb);               // xb 2^ex in [2^12, 2^13): fp16 overflows beyond 8 xb
+      m->k3_ex[(size_t)2 * d + 1] = 9 - std::ilogb(xb * xb);        // xb^2 2^ex in [2^9, 2^10): beyond 8 xb as well
+    }
+    int S = INT_MAX;
+    if (ok) {
+      for (int k = 0; k < 2 * D; ++k) if (m->wmax[(size_t)k] > 0.0f) S = std::min(S, 14 - std::ilogb(m->wmax[(size_t)k]) + m->k3_ex[(size_t)k]);
+      if (S == INT_MAX) S = 0;
+      if (S < -40 || S > 40) ok = false;
+    }
+    if (ok) {
+      double floor_sum = 0.0, bound = (double)m->gcmax;
+      for (int k = 0; k < 2 * D; ++k) {
+        const double xbk = (k & 1) ? (double)m->k3_xb[(size_t)(k >> 1)] * (double)m->k3_xb[(size_t)(k >> 1)] : (double)m->k3_xb[(size_t)(k >> 1)];
+        floor_sum += std::ldexp((double)m->wmax[(size_t)k], S - m->k3_ex[(size_t)k]) + std::ldexp(xbk, m->k3_ex[(size_t)k]);
+        bound += (double)m->wmax[(size_t)k] * xbk * ((k & 1) ? 128.0 : 16.0);
+      }
+      // (4e-6: the headroom for features outside the model's envelope costs two bits against K1s, whose planes peak at 2^14 by
+      //  construction; the fp32 chain this replaces carries ~7e-7 B, i.e. ~1e-4 at the same shapes)
+      if (!(std::ldexp(floor_sum, -25 - S) <= 4.0e-6) || !(bound <= 268435456.0)) ok = false;
+      if (ctx->opt[KHG_OPT_DEBUG]) fprintf(stderr, "[khg] K3 fp16 phase A: S %d, floor %.3g, bound %.3g -> %s\n", S, std::ldexp(floor_sum, -25 - S), bound, ok ? "on" : "off");
+    }
+    m->k3_S = ok ? S : 0;
+    m->k3_f16_ok = ok;
+    if (ok) {
+      if (!m->k3_ex_d) { rc = dev_alloc(&m->k3_ex_d, (size_t)K); if (rc) return rc; }
+      HIPCHK(hipMemcpyAsync(m->k3_ex_d, m->k3_ex.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  if (!m->k3_f16_ok) return KHG_OK;
+  for (int k = 0; k < 2 * D; ++k)
+    if (!(std::ldexp((double)xk[(size_t)k], m->k3_ex[(size_t)k]) < 65504.0)) return KHG_OK;     // a feature beyond 64 xb: fp32 phase A for this set
+  *use = true;
+  return KHG_OK;
+}
+
+static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
+  if (!ctx || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
+  if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
+  if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
+    return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");
+  if (tm->max_pdf >= m->P) return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: transition model refers to pdf-ids the model does not have");
+  int rc = wait_ali(ctx, u);
+  if (rc) return rc;
+  if (!u->frame_ids_d || u->k3_P != m->P || u->k3_tids != tm->num_tids) {
+    DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d); DEVFREE(u->frame_ids_d);
+    rc = dev_alloc(&u->pdf_count_d, (size_t)m->P);
+    if (!rc) rc = dev_alloc(&u->pdf_cursor_d, (size_t)m->P);
+    if (!rc) rc = dev_alloc(&u->pdf_start_d, (size_t)m->P + 1);
+    if (!rc) rc = dev_alloc(&u->tid_count_d, (size_t)tm->num_tids + 1);
+    if (!rc) rc = dev_alloc(&u->frame_ids_d, (size_t)u->N);
+    if (rc) return rc;
+    u->k3_P = m->P; u->k3_tids = tm->num_tids;
+  }
+  HIPCHK(hipMemsetAsync(u->pdf_count_d, 0, sizeof(int32_t) * (size_t)m->P, ctx->stream));
+  HIPCHK(hipMemsetAsync(u->tid_count_d, 0, sizeof(unsigned long long) * ((size_t)tm->num_tids + 1), ctx->stream));
+  K3Args a;
+  a.feats = u->feats_d; a.ali = u->ali_d; a.id2pdf = tm->id2pdf_d; a.num_tids = tm->num_tids;
+  a.N = u->N; a.P = m->P; a.D = m->D;
+  a.gauss_off = m->gauss_off_d; a.gconsts = m->gconsts_d; a.means_invvars = m->miv_d; a.inv_vars = m->iv_d; a.nhalf_inv_vars = m->nhiv_d;
+  a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
+  a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
+  a.occ = acc->occ(); a.mean_acc = acc->mean(); a.var_acc = acc->var(); a.trans_acc = acc->trans(); a.scalars = acc->scalars();
+  a.weight = weight; a.err_flag = ctx->err_flag_d; a.part = nullptr; a.ll_part = nullptr; a.pdf0 = 0; a.npdf = m->P; a.items = nullptr; a.item_off = nullptr;
+  a.pa_ex = nullptr; a.pa_S = 0; a.pa_scale = 1.0f; a.pa_inv = 1.0f; a.pa_c1 = 1.44269504088896340736f;
+  nparts = std::max(1, std::min(nparts, m->P));
+  if (comm && nparts > 1) { rc = ctx_comm_stream(ctx); if (rc) return rc; }
+  if (u->N > 0) {
+    const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
+    {
+      KernelTimer kt(ctx, "k3_bucket");
+      // KHG_OPT_K3_BUCKET = 1: cursor-bump scatter (bucket order depends on the atomics)
+      if (ctx->opt[KHG_OPT_K3_BUCKET] == 1 || u->N >= (int64_t)INT_MAX) {
+        hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+      } else if (ctx->opt[KHG_OPT_K3_BUCKET] == 2 && m->P <= K3_CS_MAXP) {
+        // the library's own stable counting sort (khg_k3_accstats.hip.inc: k3_cs_*; opt-in: 1.27 ms against the radix sort's 0.80 at the
+        // bench size): blocks of CB consecutive frames
+        const int nw = m->P + 1 <= 7168 ? 4 : 2;                      // waves of a placing block: nw x (P + 1 + 1024) counters of LDS
+        int64_t CB = 32768;
+        while (CB > 64 * nw * 4 && (u->N + CB - 1) / CB < 1024) CB /= 2;   // enough blocks to fill the chip on small sets
+        const int nblk = (int)((u->N + CB - 1) / CB);
+        const size_t hist_n = (size_t)nblk * ((size_t)m->P + 1);
+        if (u->cs_hist_n < hist_n) { DEVFREE(u->cs_hist_d); rc = dev_alloc(&u->cs_hist_d, hist_n); if (rc) return rc; u->cs_hist_n = hist_n; }
+        if (u->cs_tot_n < (size_t)m->P + 1) { DEVFREE(u->cs_tot_d); rc = dev_alloc(&u->cs_tot_d, (size_t)m->P + 1); if (rc) return rc; u->cs_tot_n = (size_t)m->P + 1; }
+        K3CsArgs c{u->cs_hist_d, u->cs_tot_d, (int32_t)CB, nblk};
+        const bool ldst = tm->num_tids <= K3_LDS_TIDS;
+        const size_t lds_h = sizeof(unsigned int) * ((size_t)m->P + 1 + (ldst ? (size_t)tm->num_tids + 1 : 0));
+        const size_t lds_p = sizeof(unsigned int) * (size_t)nw * ((size_t)m->P + 1 + 1024);     // per-wave counters + the run-head hash tags
+        if (lds_h > 48 * 1024) {
+          HIPCHK(hipFuncSetAttribute((const void*)k3_cs_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+          HIPCHK(hipFuncSetAttribute((const void*)k3_cs_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+        }
+        if (lds_p > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k3_cs_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        if (ldst) hipLaunchKernelGGL(k3_cs_hist<true>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
+        else hipLaunchKernelGGL(k3_cs_hist<false>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
+        hipLaunchKernelGGL(k3_cs_scan, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, c);
+        hipLaunchKernelGGL(k3_cs_starts, dim3(1), dim3(1024), 0, ctx->stream, a, c);
+        hipLaunchKernelGGL(k3_cs_place, dim3(nblk), dim3(64 * nw), lds_p, ctx->stream, a, c);
+      } else {
+        // stable sort of (pdf, frame) pairs: frames of a pdf stay in frame order; the bucket boundaries are read
+        // off the sorted keys
+        int bits = 1;
+        while ((1 << bits) <= m->P) ++bits;            // keys are 0..P
+        if (!u->sort_keys_d) {
+          rc = dev_alloc(&u->sort_keys_d, (size_t)u->N);
+          if (!rc) rc = dev_alloc(&u->sort_keys_out_d, (size_t)u->N);
+          if (!rc) rc = dev_alloc(&u->sort_vals_d, (size_t)u->N);
+          if (rc) return rc;
+        }
+        size_t need = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
+                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+        if (need > u->sort_tmp_bytes) {
+          DEVFREE(u->sort_tmp_d);
+          HIPCHK(hipMalloc(&u->sort_tmp_d, need));
+          u->sort_tmp_bytes = need;
+        }
+        if (tm->num_tids <= K3_LDS_TIDS) hipLaunchKernelGGL(k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        else hipLaunchKernelGGL(k3_sort_keys<false>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
+                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+        hipLaunchKernelGGL(k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
+      }
+    }
+    // Work items of the accumulate kernels (k3_make_items): ny_base slices per pdf, more for a pdf whose bucket is far above the
+    // average slice (2 x; silence in real transcripts).  -> the number of blocks to launch for a range of np pdfs (an upper bound
+    // from N and P alone: the bucket sizes stay on the device) in *extra_blocks; parked: the slices park images (wave forms).
+    int64_t k3_extra_blocks = 0;
+    auto make_items = [&](int ny_base, bool parked, size_t nsum1) -> int {
+      const int64_t avg = u->N / std::max(1, m->P);
+      const int target = (int)std::min<int64_t>(1 << 30, std::max<int64_t>(512, 2 * avg / ny_base));
+      const int64_t per_t = u->N / target;
+      k3_extra_blocks = std::min<int64_t>(per_t + m->P, 2 * per_t) + 1;
+      const int64_t max_items = (int64_t)m->P * ny_base + k3_extra_blocks;
+      const int64_t max_slots = !parked ? INT_MAX : ny_base > 1 ? max_items : 2 * per_t + 1;
+      if (max_items >= INT_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: too many work items");
+      if (u->k3_items_n < (size_t)max_items) {
+        DEVFREE(u->k3_items_d);
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&u->k3_items_d), sizeof(K3Item) * (size_t)max_items));
+        u->k3_items_n = (size_t)max_items;
+      }
+      if (u->k3_item_off_n < (size_t)m->P + 1) {
+        DEVFREE(u->k3_item_off_d);
+        int rc2 = dev_alloc(&u->k3_item_off_d, (size_t)m->P + 1);
+        if (rc2) return rc2;
+        u->k3_item_off_n = (size_t)m->P + 1;
+      }
+      if (parked && u->k3_part_n < (size_t)max_slots * nsum1) {
+        DEVFREE(u->k3_part_d);
+        int rc2 = dev_alloc(&u->k3_part_d, (size_t)max_slots * nsum1);
+        if (rc2) return rc2;
+        u->k3_part_n = (size_t)max_slots * nsum1;
+      }
+      hipLaunchKernelGGL(k3_make_items, dim3(1), dim3(1024), 0, ctx->stream, a, ny_base, target, (int)max_items, (int)std::min<int64_t>(max_slots, INT_MAX),
+                         reinterpret_cast<K3Item*>(u->k3_items_d), u->k3_item_off_d);
+      a.items = reinterpret_cast<const K3Item*>(u->k3_items_d); a.item_off = u->k3_item_off_d;
+      return KHG_OK;
+    };
+    int maxG = 0;
+    for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
+    const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
+    const int k3form = ctx->opt[KHG_OPT_K3_FORM];     // 1: the chunk-per-block MFMA form for every shape; 2: the VALU form
+    // the chunk-per-block MFMA form holds 16 * 4 * NBW Gaussians: NBW <= 2 at D <= 80, <= 4 at D <= 40 (the accumulators are registers)
+    const bool use_mfma = (maxG <= 128 || (maxG <= 256 && m->KQ == 10)) && k3form != 2 && m->KQ != 0;
+    const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && k3form != 1;
+    if (use_wave) {
+      // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
+      const int nb = (maxG + 15) / 16;
+      // phase A on the fp16 matrix cores where the model-derived scales hold (KHG_K3_PHASEA=f32 keeps the fp32 chain)
+      bool f16a = false;
+      // (pdfs of <= 32 Gaussians keep the fp32 chain: 40 MFMAs per tile are not worth the split, and the two-waves-per-SIMD
+      //  instantiations have no registers for the fp16 W pieces)
+      if (nb >= 3 && ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] != 1) { rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &f16a); if (rc) return rc; }
+      if (f16a) {
+        a.pa_ex = m->k3_ex_d; a.pa_S = m->k3_S;
+        a.pa_scale = std::ldexp(1.0f, m->k3_S); a.pa_inv = std::ldexp(1.0f, -m->k3_S); a.pa_c1 = std::ldexp(1.44269504088896340736f, -m->k3_S);
+      }
+      // phase B on the fp16 matrix cores as well (k3_accumulate_wave16; KHG_OPT_K3_PHASE_B = 2): where phase A's split planes exist
+      // and the weight is an ordinary number
+      const bool f16b = f16a && ctx->opt[KHG_OPT_K3_PHASE_B] == 2 && std::isfinite(weight) && std::fabs(weight) > 1.0e-30f && std::fabs(weight) < 1.0e30f;
+      if (f16b) { a.pb_SG = 13 - std::ilogb(std::fabs(weight)); a.pb_gscale = std::ldexp(1.0f, a.pb_SG); }
+      // fp32 phase A: W + the waves' planes; fp16 phase A: the waves' planes + their split planes; then the fold image
+      const size_t lds = std::max<size_t>(f16a ? sizeof(float) * (4 * 4 * 16 * 20) + 2 * (size_t)(4 * 2 * 16 * K3_XH_ROW)
+                                               : sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 4 * 16 * 20),
+                                          sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
+      const int64_t avg_tiles = (u->N / std::max(1, m->P) + 15) / 16;
+      int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, (avg_tiles + 15) / 16), (4096 + m->P - 1) / m->P));
+      if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
+      // per-pdf log-like partials (always) and, with several blocks per pdf, the slice images they park
+      const size_t nsum1 = (size_t)nb * 16 * 80 + (size_t)nb * 16 + 1;
+      if (u->k3_llpart_n < (size_t)m->P) {
+        DEVFREE(u->k3_llpart_d);
+        rc = dev_alloc(&u->k3_llpart_d, (size_t)m->P);
+        if (rc) return rc;
+        u->k3_llpart_n = (size_t)m->P;
+      }
+      rc = make_items(ny, true, nsum1);
+      if (rc) return rc;
+      HIPCHK(hipMemsetAsync(u->k3_llpart_d, 0, sizeof(double) * (size_t)m->P, ctx->stream));
+      a.ll_part = u->k3_llpart_d;
+      a.part = u->k3_part_d;
+      for (int part = 0; part < nparts; ++part) {
+      const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      a.pdf0 = p0; a.npdf = np;
+      const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
+      {
+      KernelTimer kt(ctx, "k3_accumulate");
+      // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
+      // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
+      const bool exact_b = ctx->opt[KHG_OPT_K3_PHASE_B] != 1;       // (2 = the fp16 matrix cores where they apply, else fp64)
+      // k3_accumulate_wave32: the workgroup's fp64 image + W + two x planes per wave
+      const size_t lds32 = sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16) + sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 2 * 16 * 20);
+      // k3_accumulate_wave16: per wave two tiles' phase-A planes + the phase-B planes (halves), then the split W operands
+      const size_t lds16 = std::max<size_t>(2 * (size_t)4 * (2 * (2 * 16 * K3_XH_ROW) + 2 * 2 * 40 * 36) + (size_t)nb * 3 * 2 * 64 * 16,
+                                            sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
+#define K3_WAVE_LAUNCH(NBV)                                                                                            \
+  do {                                                                                                                  \
+    if (!exact_b && lds32 > 48 * 1024)                                                                                  \
+      HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
+    if (f16b) {                                                                                                          \
+      HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave16<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
+      hipLaunchKernelGGL((k3_accumulate_wave16<NBV>), dim3(nblk), dim3(256), lds16, ctx->stream, a);                     \
+    } else if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);    \
+    else if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(nblk), dim3(256), lds, ctx->stream, a);         \
+    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(nblk), dim3(256), lds32, ctx->stream, a);                  \
+    hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a);                                 \
+  } while (0)
+      switch (nb) {
+        case 1: K3_WAVE_LAUNCH(1); break;
+        case 2: K3_WAVE_LAUNCH(2); break;
+        case 3: K3_WAVE_LAUNCH(3); break;
+        default: K3_WAVE_LAUNCH(4); break;
+      }
+#undef K3_WAVE_LAUNCH
+      }
+      if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      }
+      a.pdf0 = 0; a.npdf = m->P;
+      hipLaunchKernelGGL(k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
+    } else if (use_mfma) {
+      // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
+      const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions
+      // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
+      // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
+      int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
+      if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
+      rc = make_items(ny, false, 0);
+      if (rc) return rc;
+      for (int part = 0; part < nparts; ++part) {
+        const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+        a.pdf0 = p0; a.npdf = np;
+        const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
+        {
+          KernelTimer kt(ctx, "k3_accumulate");
+          if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 128) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 192) hipLaunchKernelGGL((k3_accumulate_mfma<10, 3>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 4>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+        }
+        if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      }
+      a.pdf0 = 0;
+    } else {
+      const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)(m->KQ ? 4 * m->KQ : (m->D | 1)) + (maxG | 1) + 4);
+      if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
+      const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : m->KQ == 20 ? (const void*)k3_accumulate<20> : (const void*)k3_accumulate<0>;
+      if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
+      rc = make_items(ny, false, 0);
+      if (rc) return rc;
+      for (int part = 0; part < nparts; ++part) {
+        const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+        a.pdf0 = p0; a.npdf = np;
+        const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
+        {
+          KernelTimer kt(ctx, "k3_accumulate");
+          if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 20) hipLaunchKernelGGL(k3_accumulate<20>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else hipLaunchKernelGGL(k3_accumulate<0>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+        }
+        if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      }
+      a.pdf0 = 0;
+    }
+    HIPCHK(hipGetLastError());
+  } else if (comm && nparts > 1) {
+    // a rank without frames launches nothing but takes part in the same collectives, in the same order, as every other rank: the
+    // sequence is a function of (P, nparts) only
+    for (int part = 0; part < nparts; ++part) {
+      const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr);
+      if (rc) return rc;
+    }
+  }
+  if (comm) {
+    // the rest of the block: all of it when nothing was pipelined, else the transition counts and the scalars; then the kernels'
+    // stream waits for the communication stream
+    if (nparts > 1) rc = accs_allreduce_pieces(ctx, acc, m, -1, 0, comm, nullptr);
+    else rc = khg_accs_allreduce(ctx, acc, comm);
+    if (rc) return rc;
+  }
+  return KHG_OK;   // asynchronous: kernel-side errors surface at khg_ctx_sync / khg_accs_download
+}
+extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc) {
+  return acc_stats_impl(ctx, m, tm, u, weight, acc, nullptr, 1);
+}
+extern "C" int khg_acc_stats_reduce(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int32_t nparts) {
+  return acc_stats_impl(ctx, m, tm, u, weight, acc, comm, nparts <= 0 ? 4 : nparts);
+}

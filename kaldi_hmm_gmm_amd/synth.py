@@ -244,3 +244,45 @@ def sample_feats_torch(model: SynthModel, frame_pdf, seed, device, chunk=1 << 22
                 out[cur: cur + n] = means[ck] + std[ck] * z[k]
             cur += n
     return out
+
+
+def host_objects(model: SynthModel):
+    """The host classes the reference's scripts take (AmDiagGmm, TransitionModel) for a synthetic model: P // 3 phones (ids 1..)
+    of three left-to-right states (self-loop 0.75 / forward 0.25, scripts/prepare_lang.py:514-560), a monophone tree -- its
+    transition-ids are make_model's (2 pdf + 1 self-loop, 2 pdf + 2 forward; pdf = 3 (phone - 1) + state).  Pdfs beyond
+    3 (P // 3) exist in the AmDiagGmm only."""
+    from . import _lib
+    import ctypes as C
+    from .context_dep import monophone_context_dependency
+    from .diag_gmm import AmDiagGmm, DiagGmm
+    from .hmm_topology import HmmTopology
+    from .transition_model import TransitionModel
+    P, D = model.num_pdfs, model.dim
+    nph = P // 3
+    s = "<Topology> <TopologyEntry> <ForPhones> " + " ".join(str(i) for i in range(1, nph + 1)) + "\n</ForPhones> "
+    for i in range(3):
+        s += f"<State> {i} <PdfClass> {i} <Transition> {i} 0.75 <Transition> {i + 1} 0.25 </State> "
+    s += "<State> 3 </State> </TopologyEntry> </Topology>"
+    topo = HmmTopology()
+    topo.read(s)
+    tree = monophone_context_dependency(list(range(1, nph + 1)), topo.get_phone_to_num_pdf_classes())
+    tm = TransitionModel(ctx_dep=tree, hmm_topo=topo)
+    gc = np.zeros(model.weights.shape[0], np.float32)
+    _lib.check(_lib.lib.khg_compute_gconsts(P, D, _lib.ptr(model.gauss_off, C.c_int32), _lib.ptr(model.weights, C.c_float),
+                                            _lib.ptr(model.inv_vars, C.c_float), _lib.ptr(model.means_invvars, C.c_float),
+                                            _lib.ptr(gc, C.c_float), None))
+    am = AmDiagGmm()
+    am.init(DiagGmm(nmix=1, dim=D), P)
+    am.set_flat(model.gauss_off, model.weights, gc, model.means_invvars, model.inv_vars)
+    return am, tm
+
+
+def utt_fst(graphs, u):
+    """Utterance u of a CSR graph set as the StdVectorFst the reference's scripts pass around."""
+    from .fst import StdVectorFst
+    so = graphs["state_off"]
+    s0, s1 = int(so[u]), int(so[u + 1])
+    ao = graphs["arc_off"][s0: s1 + 1]
+    a0, a1 = int(ao[0]), int(ao[-1])
+    return StdVectorFst.from_csr(int(graphs["start"][u]), (ao - a0).astype(np.int64), graphs["ilabel"][a0:a1], graphs["olabel"][a0:a1],
+                                 graphs["weight"][a0:a1], graphs["nextstate"][a0:a1], graphs["final"][s0:s1])
