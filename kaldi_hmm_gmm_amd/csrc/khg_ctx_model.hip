@@ -1,6 +1,8 @@
 // kaldi_hmm_gmm_amd/csrc/khg_ctx_model.hip -- C-ABI (include/khg_hip.h): errors, the per-device context and its options, the
 // acoustic-model handle (row-major parameters + the fp32 K1 tile image, packed on the device) and the transition table.  gfx950 only.
 #include "khg_internal.hpp"
+
+#include <mutex>
 #include "khg_k1_loglikes.hip.inc"     // the tile geometry (khg_row_floats / khg_tile_floats) k0_pack_tiles shares with K1
 
 // ------------------------------------------------------------------------------------------
@@ -8,6 +10,60 @@ static thread_local std::string g_err;
 extern "C" const char* khg_last_error(void) { return g_err.c_str(); }
 int khg_set_error(int code, const std::string& msg) { g_err = msg; return code; }  // shared with khg_host.cpp
 extern "C" int khg_version(void) { return 100; }
+
+// ---- the small-set scratch arena (KhgArena, khg_internal.hpp) ----------------------------------------------------------------
+static std::mutex g_ctx_mu;
+static std::vector<khg_ctx*> g_ctxs;          // live contexts: khg_arena_release finds the owner of a pointer here
+static constexpr size_t KHG_ARENA_BYTES = size_t(24) << 20;
+void* arena_alloc(khg_ctx* ctx, size_t bytes) {
+  KhgArena& a = ctx->arena;
+  if (!a.dev) {
+    if (a.cap == SIZE_MAX) return nullptr;                       // could not be made: do not try again
+    void *d = nullptr, *h = nullptr;
+    if (hipMalloc(&d, KHG_ARENA_BYTES) != hipSuccess || hipHostMalloc(&h, KHG_ARENA_BYTES, hipHostMallocDefault) != hipSuccess) {
+      if (d) (void)hipFree(d);
+      (void)hipGetLastError();
+      a.cap = SIZE_MAX;
+      return nullptr;
+    }
+    a.dev = static_cast<char*>(d); a.host = static_cast<char*>(h); a.cap = KHG_ARENA_BYTES; a.top = a.base = 0;
+  }
+  bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+  if (a.top + bytes > a.cap) return nullptr;
+  void* p = a.dev + a.top;
+  a.top += bytes;
+  ++a.live;
+  return p;
+}
+void arena_mark_dirty(khg_ctx* ctx, const void* dev_ptr, size_t bytes) {
+  KhgArena& a = ctx->arena;
+  const size_t lo = (size_t)((const char*)dev_ptr - a.dev), hi = lo + bytes;
+  // allocations are 256-byte aligned: a range that starts within 256 bytes of the previous one's end belongs to the next allocation
+  // (nothing un-staged lies between them) and joins it; anything else -- an allocation a kernel may already have written -- is left out
+  if (!a.dirty.empty() && lo >= a.dirty.back().second && lo - a.dirty.back().second < 256) a.dirty.back().second = hi;
+  else a.dirty.emplace_back(lo, hi);
+}
+int arena_flush(khg_ctx* ctx) {
+  KhgArena& a = ctx->arena;
+  if (a.dirty.empty()) return KHG_OK;
+  for (const auto& r : a.dirty)
+    HIPCHK(hipMemcpyAsync(a.dev + r.first, a.host + r.first, r.second - r.first, hipMemcpyHostToDevice, ctx->stream));
+  a.dirty.clear();
+  return KHG_OK;
+}
+bool khg_arena_release(void* p) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  for (khg_ctx* c : g_ctxs) {
+    KhgArena& a = c->arena;
+    if (!a.owns(p)) continue;
+    if (--a.live <= 0) { a.live = 0; a.top = a.base; a.dirty.clear(); }   // the owners waited for their streams before releasing
+    return true;
+  }
+  return false;
+}
+void khg_dev_free(void* p) {
+  if (p && !khg_arena_release(p)) (void)hipFree(p);
+}
 
 static void ctx_defaults_from_env(khg_ctx* c);
 extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
@@ -30,8 +86,10 @@ extern "C" int khg_ctx_create(int device, void* stream, khg_ctx** out) {
   ctx_defaults_from_env(c);
   int rc = dev_alloc(&c->err_flag_d, 1);
   if (!rc) rc = dev_alloc(&c->dump_d, 256);
+  if (!rc && hipHostMalloc(reinterpret_cast<void**>(&c->err_host), 256, hipHostMallocDefault) != hipSuccess) rc = khg_set_error(KHG_E_HIP, "khg_ctx_create: hipHostMalloc failed");
   if (rc) { delete c; return rc; }
   HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.push_back(c); }
   *out = c;
   return KHG_OK;
 }
@@ -39,7 +97,11 @@ extern "C" int khg_ctx_destroy(khg_ctx* c) {
   if (!c) return KHG_OK;
   (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->sides) (void)hipStreamSynchronize(s);
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
   DEVFREE(c->err_flag_d); DEVFREE(c->dump_d);
+  if (c->err_host) (void)hipHostFree(c->err_host);
+  if (c->arena.dev) (void)hipFree(c->arena.dev);
+  if (c->arena.host) (void)hipHostFree(c->arena.host);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   for (auto& s : c->sides) (void)hipStreamDestroy(s);
   if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
@@ -126,10 +188,12 @@ extern "C" int khg_ctx_sync(khg_ctx* c) {
 }
 // read-and-clear the device error word; maps bits to the reference's exceptions
 int check_err_flag(khg_ctx* c, const char* where) {
-  int32_t f = 0;
-  for (auto& s : c->sides) HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipMemcpyAsync(&f, c->err_flag_d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+  for (int i = 0; i < khg_ctx::NSIDE; ++i)
+    if (c->side_dirty[i]) { HIPCHK(hipStreamSynchronize(c->sides[i])); c->side_dirty[i] = false; }
+  HIPCHK(hipMemcpyAsync(c->err_host, c->err_flag_d, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->pageable_pending = false;
+  const int32_t f = *c->err_host;
   if (f) {
     HIPCHK(hipMemsetAsync(c->err_flag_d, 0, sizeof(int32_t), c->stream));
     if (f & 1) return khg_set_error(KHG_E_RUNTIME, std::string(where) + ": Invalid answer (overflow or invalid variances/features?)");
@@ -184,6 +248,7 @@ __global__ void k0_nhalf(const float* __restrict__ iv, int64_t n, float* __restr
 // 113 MB image, no extra copies.  Used by khg_model_create and after the device M-step.
 int model_pack(khg_ctx* ctx, khg_model* m) {
   const int P = m->P, D = m->D;
+  ++m->version;
   m->pdf_tile_off.resize((size_t)P + 1);
   int nt = 0;
   for (int p = 0; p < P; ++p) { m->pdf_tile_off[p] = nt; nt += (m->gauss_off[p + 1] - m->gauss_off[p] + 31) / 32; }
@@ -237,6 +302,17 @@ int model_pack(khg_ctx* ctx, khg_model* m) {
   return rc;
 }
 
+// live model handles by serial: an utterance set scored in the BAND form keeps (serial, version) of its model and khg_align asks here
+// whether that model still exists before the repair launch dereferences it
+static std::mutex g_model_mu;
+static std::vector<khg_model*> g_models;
+static uint64_t g_model_serial = 0;
+khg_model* khg_model_lookup(uint64_t serial) {
+  std::lock_guard<std::mutex> lk(g_model_mu);
+  for (khg_model* m : g_models) if (m->serial == serial) return m;
+  return nullptr;
+}
+
 extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_t* gauss_off,
                                 const float* gconsts, const float* miv, const float* iv, khg_model** out) {
   if (!ctx || !out || P <= 0 || D <= 0 || !gauss_off || !gconsts || !miv || !iv)
@@ -262,11 +338,13 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
   if (!rc) rc = up(&m->iv_d, iv, (size_t)m->sumG * D);
   if (!rc) rc = model_pack(ctx, m);   // ends with a stream sync: the caller's arrays are free after this
   if (rc) { khg_model_destroy(m); return rc; }
+  { std::lock_guard<std::mutex> lk(g_model_mu); m->serial = ++g_model_serial; g_models.push_back(m); }
   *out = m;
   return KHG_OK;
 }
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
+  { std::lock_guard<std::mutex> lk(g_model_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
   m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
   DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);

@@ -19,11 +19,9 @@ DecodableAmDiagGmmUnmapped::DecodableAmDiagGmmUnmapped(std::shared_ptr<AmDiagGmm
 const std::vector<float>& DecodableAmDiagGmmUnmapped::Scores() const {
   if (ll_.empty() && T_ > 0) {
     KHG_REQUIRE(am_->Dim() == D_, "Dim mismatch: data dim = " + std::to_string(D_) + " vs. model dim = " + std::to_string(am_->Dim()));
-    std::vector<int32_t> go, pdfs((size_t)am_->NumPdfs());
-    std::vector<float> gc, miv, iv;
-    am_->Flat(&go, &gc, nullptr, &miv, &iv);
+    std::vector<int32_t> pdfs((size_t)am_->NumPdfs());
     for (int p = 0; p < am_->NumPdfs(); ++p) pdfs[(size_t)p] = p;
-    ll_ = GpuLoglikes(am_->NumPdfs(), D_, go.data(), gc.data(), miv.data(), iv.data(), feats_.data(), T_, pdfs.data(), am_->NumPdfs());
+    ll_ = GpuLoglikesOn(am_->DeviceModel(DefaultCtx()), D_, feats_.data(), T_, pdfs.data(), am_->NumPdfs());
   }
   return ll_;
 }
@@ -38,8 +36,6 @@ bool DecodableAmDiagGmmUnmapped::IsLastFrame(int frame) const {
 }
 
 namespace {
-struct ModelH { khg_model* h = nullptr; ~ModelH() { if (h) khg_model_destroy(h); } };
-struct TmH { khg_tm* h = nullptr; ~TmH() { if (h) khg_tm_destroy(h); } };
 struct UttsH { khg_utts* h = nullptr; ~UttsH() { if (h) khg_utts_destroy(h); } };
 std::string G(double x) { char b[64]; std::snprintf(b, sizeof(b), "%g", x); return b; }
 }  // namespace
@@ -52,20 +48,26 @@ std::vector<AlignResult> AlignBatch(const AmDiagGmm& am, const TransitionModel& 
   const int n_utt = (int)feats.size(), D = am.Dim();
   KHG_REQUIRE((int)nframes.size() == n_utt && (int)g.start.size() == n_utt && (int)g.state_off.size() == n_utt + 1, "AlignBatch: one graph and one feature matrix per utterance");
   khg_ctx* ctx = DefaultCtx();
-  std::vector<int32_t> go;
-  std::vector<float> gc, miv, iv;
-  am.Flat(&go, &gc, nullptr, &miv, &iv);
-  ModelH dm; TmH dt; UttsH us;
-  CApi(khg_model_create(ctx, am.NumPdfs(), D, go.data(), gc.data(), miv.data(), iv.data(), &dm.h));
-  std::vector<int32_t> id2pdf(tm.id2pdf().begin(), tm.id2pdf().end());
-  CApi(khg_tm_create(ctx, tm.NumTransitionIds(), id2pdf.data(), &dt.h));
+  // the model and the transition table live on the device across calls: cached on the host objects, uploaded again only when they
+  // changed (AmDiagGmm::DeviceModel / TransitionModel::DeviceTm) -- the scripts call this once per utterance
+  struct { khg_model* h; } dm{am.DeviceModel(ctx)};
+  struct { khg_tm* h; } dt{tm.DeviceTm(ctx)};
+  UttsH us;
   CApi(khg_tm_set_trans_cost(dt.h, trans_cost));
   std::vector<int64_t> frame_off((size_t)n_utt + 1, 0);
   for (int u = 0; u < n_utt; ++u) frame_off[(size_t)u + 1] = frame_off[(size_t)u] + nframes[(size_t)u];
-  std::vector<float> all((size_t)std::max<int64_t>(frame_off[(size_t)n_utt], 1) * D);
-  for (int u = 0; u < n_utt; ++u)
-    if (nframes[(size_t)u] > 0) std::memcpy(all.data() + (size_t)frame_off[(size_t)u] * D, feats[(size_t)u], sizeof(float) * (size_t)nframes[(size_t)u] * D);
-  CApi(khg_utts_create(ctx, dt.h, n_utt, D, frame_off.data(), all.data(), nullptr, g.state_off.data(), g.start.data(), g.arc_off.data(), g.ilabel.data(),
+  std::vector<float> all;
+  const float* fp = nullptr;
+  if (n_utt == 1) fp = feats[0];            // one utterance: its matrix as it is
+  else {
+    all.resize((size_t)std::max<int64_t>(frame_off[(size_t)n_utt], 1) * D);
+    for (int u = 0; u < n_utt; ++u)
+      if (nframes[(size_t)u] > 0) std::memcpy(all.data() + (size_t)frame_off[(size_t)u] * D, feats[(size_t)u], sizeof(float) * (size_t)nframes[(size_t)u] * D);
+    fp = all.data();
+  }
+  static const float kNoFrames[1] = {0.0f};
+  if (!fp) fp = kNoFrames;
+  CApi(khg_utts_create(ctx, dt.h, n_utt, D, frame_off.data(), fp, nullptr, g.state_off.data(), g.start.data(), g.arc_off.data(), g.ilabel.data(),
                        g.olabel.data(), g.weight.data(), g.nextstate.data(), g.final_w.data(), &us.h));
   // only the cells a decoder token can read; with a wide beam (few failed beam certificates to repair) also not the cells that only
   // tokens past any accepting path read (khg_loglikes_band: identical alignments, ~13 % fewer cells on chain graphs)
@@ -115,6 +117,48 @@ std::vector<AlignResult> AlignBatch(const AmDiagGmm& am, const TransitionModel& 
     }
   }
   return out;
+}
+
+// scripts/gmm_acc_stats_ali.py:46-58 through K3, into the accumulators' device block (khg_host_gmm.hpp)
+double AccumAmDiagGmm::AccumulateAli(const AmDiagGmm& model, const TransitionModel& tm, const float* feats, const int64_t* frame_off, int n_utt,
+                                     const int32_t* ali, float weight) {
+  KHG_REQUIRE(n_utt >= 1 && frame_off && frame_off[0] == 0, "AccumulateAli: bad arguments");
+  const int64_t N = frame_off[n_utt];
+  if (N == 0) return 0.0;
+  KHG_REQUIRE(NumAccs() == model.NumPdfs(), "gmm_accs.NumAccs() == am_gmm.NumPdfs() assertion failed");
+  const int D = model.Dim(), nt = tm.NumTransitionIds();
+  for (int64_t t = 0; t < N; ++t) KHG_REQUIRE(ali[t] >= 1 && ali[t] <= nt, "gmm_acc_stats_ali: transition-id out of range");
+  khg_ctx* ctx = DefaultCtx();
+  khg_model* dm = model.DeviceModel(ctx);
+  khg_tm* dt = tm.DeviceTm(ctx);
+  const uint64_t mv = model.Version();
+  if (dev_ && (dev_->ctx != ctx || dev_->model_version != mv || dev_->num_tids != nt)) {
+    // another model (or the same one after an update that may have moved its layout): what is pending belongs to the old layout
+    Flush();
+    dev_.reset();
+  }
+  if (!dev_) {
+    auto d = std::make_shared<Dev>();
+    d->ctx = ctx; d->model_version = mv; d->num_tids = nt; d->D = D;
+    d->gauss_off.assign((size_t)model.NumPdfs() + 1, 0);
+    for (int p = 0; p < model.NumPdfs(); ++p) {
+      const int G = model.GetPdf(p)->NumGauss();
+      KHG_REQUIRE(accs_[(size_t)p]->NumGauss() == G && accs_[(size_t)p]->Dim() == D, "gmm_accs was not initialised for this model (AccumAmDiagGmm.init)");
+      d->gauss_off[(size_t)p + 1] = d->gauss_off[(size_t)p] + G;
+    }
+    CApi(khg_accs_create(ctx, dm, dt, &d->h));
+    dev_ = d;
+  }
+  UttsH us;
+  CApi(khg_utts_create(ctx, nullptr, n_utt, D, frame_off, feats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &us.h));
+  CApi(khg_ali_upload(ctx, us.h, ali));
+  CApi(khg_acc_stats(ctx, dm, dt, us.h, weight, dev_->h));
+  dev_->pending = true;
+  double sc[8];
+  CApi(khg_accs_download_trans(ctx, dev_->h, nullptr, sc));      // the 8 scalars: [frames, log-like, ...] running totals of the block
+  const double ll = sc[1] - dev_->seen_ll;
+  dev_->seen_frames = sc[0]; dev_->seen_ll = sc[1];
+  return ll;
 }
 
 }  // namespace khg

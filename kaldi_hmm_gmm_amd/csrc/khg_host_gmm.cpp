@@ -35,8 +35,14 @@ void SetDefaultCtx(khg_ctx* borrowed) {
 std::vector<float> GpuLoglikes(int P, int D, const int32_t* gauss_off, const float* gconsts, const float* miv, const float* iv,
                                const float* feats, int64_t N, const int32_t* pdfs, int npdf) {
   khg_ctx* ctx = DefaultCtx();
-  ModelH m; UttsH u;
+  ModelH m;
   CApi(khg_model_create(ctx, P, D, gauss_off, gconsts, miv, iv, &m.h));
+  return GpuLoglikesOn(m.h, D, feats, N, pdfs, npdf);
+}
+std::vector<float> GpuLoglikesOn(khg_model* model, int D, const float* feats, int64_t N, const int32_t* pdfs, int npdf) {
+  khg_ctx* ctx = DefaultCtx();
+  struct { khg_model* h; } m{model};
+  UttsH u;
   const int64_t fo[2] = {0, N};
   CApi(khg_utts_create(ctx, nullptr, 1, D, fo, feats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &u.h));
   CApi(khg_utts_set_pdf_list(u.h, npdf, pdfs));
@@ -153,6 +159,7 @@ std::vector<int32_t> GetSplitTargetsD(const std::vector<float>& occs, int32_t ta
 
 // ---- DiagGmm ----------------------------------------------------------------------------------------------------------
 void DiagGmm::Resize(int nmix, int dim) {
+  Touch();
   KHG_REQUIRE(nmix >= 0 && dim >= 0, "DiagGmm::Resize: negative size");
   G_ = nmix; D_ = dim;
   gconsts_.assign((size_t)nmix, 0.0f);
@@ -181,6 +188,7 @@ DiagGmm::DiagGmm(const std::vector<std::pair<float, const DiagGmm*>>& gmms) {
   ComputeGconsts();
 }
 void DiagGmm::SetRaw(int G, int D, const float* w, const float* iv, const float* miv, const float* gc) {
+  Touch();
   G_ = G; D_ = D;
   weights_.assign(w, w + G);
   inv_vars_.assign(iv, iv + (size_t)G * D);
@@ -199,16 +207,19 @@ std::vector<float> DiagGmm::GetVars() const {
   return v;
 }
 void DiagGmm::SetWeights(const float* w, size_t n) {
+  Touch();
   KHG_REQUIRE((int)n == G_, "weights_.size() == w.size() assertion failed");
   weights_.assign(w, w + n);
   valid_gconsts_ = false;
 }
 void DiagGmm::SetMeans(const float* m, size_t rows, size_t cols) {
+  Touch();
   KHG_REQUIRE((int)rows == G_ && (int)cols == D_, "SetMeans: shape mismatch");
   for (size_t i = 0; i < means_invvars_.size(); ++i) means_invvars_[i] = m[i] * inv_vars_[i];
   valid_gconsts_ = false;
 }
 void DiagGmm::SetInvVars(const float* v, size_t rows, size_t cols) {
+  Touch();
   KHG_REQUIRE((int)rows == G_ && (int)cols == D_, "SetInvVars: shape mismatch");
   for (size_t i = 0; i < inv_vars_.size(); ++i) {
     means_invvars_[i] = means_invvars_[i] / inv_vars_[i] * v[i];
@@ -217,21 +228,25 @@ void DiagGmm::SetInvVars(const float* v, size_t rows, size_t cols) {
   valid_gconsts_ = false;
 }
 void DiagGmm::SetInvVarsAndMeans(const float* v, const float* m, size_t rows, size_t cols) {
+  Touch();
   KHG_REQUIRE((int)rows == G_ && (int)cols == D_, "SetInvVarsAndMeans: shape mismatch");
   for (size_t i = 0; i < inv_vars_.size(); ++i) { inv_vars_[i] = v[i]; means_invvars_[i] = m[i] * v[i]; }
   valid_gconsts_ = false;
 }
 void DiagGmm::SetComponentWeight(int g, float w) {
+  Touch();
   KHG_REQUIRE(w > 0.0f && g < G_ && g >= 0, "SetComponentWeight assertion failed");
   weights_[(size_t)g] = w;
   valid_gconsts_ = false;
 }
 void DiagGmm::SetComponentMean(int g, const float* v, size_t n) {
+  Touch();
   KHG_REQUIRE(g >= 0 && g < G_ && (int)n == D_, "SetComponentMean: bad index or size");
   for (int d = 0; d < D_; ++d) means_invvars_[(size_t)g * D_ + d] = inv_vars_[(size_t)g * D_ + d] * v[d];
   valid_gconsts_ = false;
 }
 void DiagGmm::SetComponentInvVar(int g, const float* v, size_t n) {
+  Touch();
   KHG_REQUIRE(g >= 0 && g < G_ && (int)n == D_, "SetComponentInvVar: bad index or size");
   for (int d = 0; d < D_; ++d) {
     const size_t k = (size_t)g * D_ + d;
@@ -253,6 +268,7 @@ std::vector<float> DiagGmm::GetComponentVariance(int g) const {
   return v;
 }
 void DiagGmm::RemoveComponent(int g, bool renorm) {
+  Touch();
   KHG_REQUIRE(g >= 0 && g < G_, "RemoveComponent: index out of range");
   KHG_REQUIRE(G_ != 1, "Attempting to remove the only remaining component.");
   weights_.erase(weights_.begin() + g);
@@ -272,6 +288,7 @@ void DiagGmm::RemoveComponents(std::vector<int> gauss, bool renorm) {
   for (size_t i = 0; i < gauss.size(); ++i) RemoveComponent(gauss[i] - (int)i, renorm);
 }
 int DiagGmm::ComputeGconsts() {
+  Touch();
   const int32_t go[2] = {0, G_};
   int32_t nb = 0;
   gconsts_.resize((size_t)G_);
@@ -375,6 +392,7 @@ float DiagGmm::GaussianSelectionPreselect(const float* data, size_t n, const std
 }
 
 void DiagGmm::Split(int target, float perturb_factor, std::vector<int>* history, const RandnFn& randn) {
+  Touch();
   int cur = G_;
   KHG_REQUIRE(!(target < cur || cur == 0), "Cannot split from " + std::to_string(cur) + " to " + std::to_string(target) + " components");
   if (target == cur) return;
@@ -406,6 +424,7 @@ void DiagGmm::Split(int target, float perturb_factor, std::vector<int>* history,
   ComputeGconsts();
 }
 std::vector<int> DiagGmm::Merge(int target) {
+  Touch();
   int32_t G = G_, nh = 0;
   std::vector<float> w = weights_, miv = means_invvars_, iv = inv_vars_, gc((size_t)G_, 0.0f);
   std::vector<int32_t> hist((size_t)2 * std::max(G_, 1));
@@ -421,6 +440,7 @@ std::vector<int> DiagGmm::Merge(int target) {
   return std::vector<int>(hist.begin(), hist.begin() + nh);
 }
 void DiagGmm::Perturb(float perturb_factor, const RandnFn& randn) {
+  Touch();
   std::vector<float> rv(means_invvars_.size());
   randn(rv.data(), (size_t)G_, (size_t)D_);
   for (size_t i = 0; i < rv.size(); ++i) {
@@ -448,6 +468,7 @@ std::vector<float> DiagGmm::Generate(const RandnFn& randn) const {
   return out;
 }
 void DiagGmm::Interpolate(float rho_f, const DiagGmm& src, int flags) {
+  Touch();
   KHG_REQUIRE(G_ == src.G_ && D_ == src.D_, "NumGauss() == source.NumGauss() && Dim() == source.Dim() assertion failed");
   // DiagGmmNormal of both (double), csrc/diag-gmm-normal.cc:14-20
   const size_t n = inv_vars_.size();
@@ -476,17 +497,38 @@ void DiagGmm::Interpolate(float rho_f, const DiagGmm& src, int flags) {
 
 // ---- AmDiagGmm --------------------------------------------------------------------------------------------------------
 void AmDiagGmm::Init(const DiagGmm& proto, int num_pdfs) {
+  struct_version_ = NextVersion();
   pdfs_.clear();
   for (int i = 0; i < num_pdfs; ++i) pdfs_.push_back(std::make_shared<DiagGmm>(proto));
 }
 void AmDiagGmm::AddPdf(const DiagGmm& gmm) {
   KHG_REQUIRE(pdfs_.empty() || gmm.Dim() == Dim(), "gmm.Dim() == this->Dim() assertion failed");
+  struct_version_ = NextVersion();
   pdfs_.push_back(std::make_shared<DiagGmm>(gmm));
 }
 void AmDiagGmm::CopyFromAmDiagGmm(const AmDiagGmm& o) {
   std::vector<std::shared_ptr<DiagGmm>> n;
   for (auto& p : o.pdfs_) n.push_back(std::make_shared<DiagGmm>(*p));
   pdfs_.swap(n);
+  struct_version_ = NextVersion();
+}
+uint64_t AmDiagGmm::Version() const {
+  uint64_t v = struct_version_;
+  for (auto& p : pdfs_) v = std::max(v, p->version());
+  return v;
+}
+khg_model* AmDiagGmm::DeviceModel(khg_ctx* ctx) const {
+  std::lock_guard<std::mutex> lk(dev_->mu);
+  const uint64_t v = Version();
+  if (dev_->h && dev_->ctx == ctx && dev_->version == v) return dev_->h;
+  dev_->Release();                          // the old image's HBM first
+  KHG_REQUIRE(NumPdfs() > 0, "AmDiagGmm: no pdfs");
+  std::vector<int32_t> go;
+  std::vector<float> gc, miv, iv;
+  Flat(&go, &gc, nullptr, &miv, &iv);
+  CApi(khg_model_create(ctx, NumPdfs(), Dim(), go.data(), gc.data(), miv.data(), iv.data(), &dev_->h));
+  dev_->ctx = ctx; dev_->version = v;
+  return dev_->h;
 }
 void AmDiagGmm::SplitByCount(const std::vector<float>& occs, int target, float perturb, float power, double min_count, const RandnFn& randn) {
   KHG_REQUIRE((int)occs.size() == NumPdfs(), "state_occs.size() == NumPdfs() assertion failed");
@@ -756,7 +798,17 @@ std::pair<float, float> MapAmDiagGmmUpdate(const MapDiagGmmOptions& cfg, const A
 }
 
 // ---- AccumAmDiagGmm ---------------------------------------------------------------------------------------------------
+AccumAmDiagGmm& AccumAmDiagGmm::operator=(const AccumAmDiagGmm& o) {
+  if (this == &o) return *this;
+  o.Flush();
+  DropDevice();
+  accs_.clear();
+  for (auto& a : o.accs_) accs_.push_back(std::make_shared<AccumDiagGmm>(*a));
+  total_frames_ = o.total_frames_; total_log_like_ = o.total_log_like_;
+  return *this;
+}
 void AccumAmDiagGmm::Init(const AmDiagGmm& model, int dim, int flags) {
+  DropDevice();
   accs_.clear();
   for (int i = 0; i < model.NumPdfs(); ++i) {
     auto a = std::make_shared<AccumDiagGmm>();
@@ -765,6 +817,7 @@ void AccumAmDiagGmm::Init(const AmDiagGmm& model, int dim, int flags) {
   }
 }
 float AccumAmDiagGmm::TotStatsCount() const {
+  Flush();
   double s = 0.0;
   for (auto& a : accs_) s += NpSum(a->occupancy().data(), a->occupancy().size());
   return (float)s;
@@ -798,12 +851,14 @@ void AccumAmDiagGmm::AccumulateForGaussian(const AmDiagGmm& am, const float* dat
 }
 void AccumAmDiagGmm::Add(float scale, const AccumAmDiagGmm& other) {
   KHG_REQUIRE(NumAccs() == other.NumAccs(), "num_accs == other.NumAccs() assertion failed");
+  Flush(); other.Flush();
   const double s = (double)scale;
   total_frames_ += s * other.total_frames_;
   total_log_like_ += s * other.total_log_like_;
   for (size_t i = 0; i < accs_.size(); ++i) accs_[i]->Add(scale, *other.accs_[i]);
 }
 void AccumAmDiagGmm::Scale(float scale) {
+  Flush();
   for (auto& a : accs_) a->Scale(scale, a->Flags());
   total_frames_ *= (double)scale;
   total_log_like_ *= (double)scale;
@@ -819,7 +874,23 @@ void AccumAmDiagGmm::AddDeviceStats(const int32_t* go, const double* occ, const 
   total_log_like_ += total_log_like;
 }
 
+// pending device sums -> the host accumulators: one download of the block, added pdf by pdf; the device block is zero afterwards
+void AccumAmDiagGmm::Flush() const {
+  if (!dev_ || !dev_->pending) return;
+  Dev& d = *dev_;
+  int64_t n = 0;
+  CApi(khg_accs_size(d.h, &n));
+  std::vector<double> buf((size_t)n);
+  CApi(khg_accs_download(d.ctx, d.h, buf.data()));
+  CApi(khg_accs_zero(d.ctx, d.h));
+  const size_t sumG = (size_t)d.gauss_off.back(), D = (size_t)d.D;
+  const size_t sc = sumG + 2 * sumG * D + (size_t)d.num_tids + 1;
+  d.pending = false; d.seen_frames = 0.0; d.seen_ll = 0.0;
+  const_cast<AccumAmDiagGmm*>(this)->AddDeviceStats(d.gauss_off.data(), buf.data(), buf.data() + sumG, buf.data() + sumG + sumG * D, (int)D, buf[sc], buf[sc + 1]);
+}
+
 MleUpdateResult MleAmDiagGmmUpdate(const MleDiagGmmOptions& cfg, const AccumAmDiagGmm& acc, int flags, AmDiagGmm* am) {
+  acc.Flush();
   KHG_REQUIRE(acc.NumAccs() == am->NumPdfs(), "am_diag_gmm_acc.NumAccs() == am_gmm->NumPdfs() assertion failed");
   KHG_REQUIRE(acc.Dim() == am->Dim(), "accumulator / model dimension mismatch (ResizeModel path is not supported)");
   KHG_REQUIRE(acc.NumAccs() > 0, "am_diag_gmm_acc.NumAccs() > 0 assertion failed");

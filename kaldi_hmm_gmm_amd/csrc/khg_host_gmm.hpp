@@ -15,7 +15,9 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <queue>
 #include <stdexcept>
 #include <string>
@@ -58,6 +60,8 @@ void SetDefaultCtx(khg_ctx* borrowed); // the Python side hands over the context
 // K1 for one feature matrix: -> [npdf][N] log-likelihoods of every frame under the listed pdfs of a flat model
 std::vector<float> GpuLoglikes(int P, int D, const int32_t* gauss_off, const float* gconsts, const float* miv, const float* iv,
                                const float* feats, int64_t N, const int32_t* pdfs, int npdf);
+// the same on a model that is on the device already (AmDiagGmm::DeviceModel)
+std::vector<float> GpuLoglikesOn(khg_model* model, int D, const float* feats, int64_t N, const int32_t* pdfs, int npdf);
 struct GpuStats {
   std::vector<double> occ, mean_acc, var_acc;
   double total_frames = 0.0, total_log_like = 0.0;
@@ -79,15 +83,21 @@ std::vector<int32_t> GetSplitTargets(const std::vector<float>& state_occs, int32
 // the same with min_count as the double a Python caller passes (the comparison (n + 1) * min_count >= occ is made in double)
 std::vector<int32_t> GetSplitTargetsD(const std::vector<float>& state_occs, int32_t target_components, float power, double min_count);
 
+// Every mutation of a DiagGmm / of an AmDiagGmm's list of pdfs takes a fresh value of ONE process-wide counter, so "the largest
+// version among the parts" changes whenever any part changed: what AmDiagGmm::DeviceModel keys its cached device handle by.
+inline uint64_t NextVersion() { static std::atomic<uint64_t> g{1}; return ++g; }
+
 // ---- csrc/diag-gmm.h ---------------------------------------------------------------------------------------------------
 class DiagGmm {
  public:
   DiagGmm() = default;
   DiagGmm(int nmix, int dim) { Resize(nmix, dim); }
+  uint64_t version() const { return version_; }
+  void Touch() { version_ = NextVersion(); }
   // the weighted concatenation of several mixtures, gconsts computed (csrc/diag-gmm.cc:68-101)
   explicit DiagGmm(const std::vector<std::pair<float, const DiagGmm*>>& gmms);
   void Resize(int nmix, int dim);                              // csrc/diag-gmm.cc:30-47 (vars = 1)
-  void CopyFromDiagGmm(const DiagGmm& o) { *this = o; }
+  void CopyFromDiagGmm(const DiagGmm& o) { *this = o; Touch(); }
   int NumGauss() const { return G_; }
   int Dim() const { return D_; }
   bool ValidGconsts() const { return valid_gconsts_; }
@@ -95,11 +105,11 @@ class DiagGmm {
   const std::vector<float>& weights() const { return weights_; }
   const std::vector<float>& inv_vars() const { return inv_vars_; }
   const std::vector<float>& means_invvars() const { return means_invvars_; }
-  std::vector<float>& mutable_gconsts() { return gconsts_; }
-  std::vector<float>& mutable_weights() { return weights_; }
-  std::vector<float>& mutable_inv_vars() { return inv_vars_; }
-  std::vector<float>& mutable_means_invvars() { return means_invvars_; }
-  void set_valid_gconsts(bool v) { valid_gconsts_ = v; }
+  std::vector<float>& mutable_gconsts() { Touch(); return gconsts_; }
+  std::vector<float>& mutable_weights() { Touch(); return weights_; }
+  std::vector<float>& mutable_inv_vars() { Touch(); return inv_vars_; }
+  std::vector<float>& mutable_means_invvars() { Touch(); return means_invvars_; }
+  void set_valid_gconsts(bool v) { Touch(); valid_gconsts_ = v; }
   // raw replacement of all parameters (unpickling, the flat store of AmDiagGmm, M-step results)
   void SetRaw(int G, int D, const float* w, const float* iv, const float* miv, const float* gc /* may be NULL */);
   std::vector<float> GetMeans() const;                         // :956-958
@@ -136,6 +146,7 @@ class DiagGmm {
  private:
   int G_ = 0, D_ = 0;
   bool valid_gconsts_ = false;
+  uint64_t version_ = NextVersion();
   std::vector<float> gconsts_, weights_, inv_vars_, means_invvars_;   // [G], [G], [G][D], [G][D]
 };
 
@@ -159,11 +170,25 @@ class AmDiagGmm {
   // flat ragged view used by the device path (gconsts must be valid)
   void Flat(std::vector<int32_t>* go, std::vector<float>* gc, std::vector<float>* w, std::vector<float>* miv, std::vector<float>* iv) const;
   void SetFlat(const int32_t* go, const float* w, const float* gc, const float* miv, const float* iv);
-  std::vector<std::shared_ptr<DiagGmm>>& pdfs() { return pdfs_; }
+  std::vector<std::shared_ptr<DiagGmm>>& pdfs() { struct_version_ = NextVersion(); return pdfs_; }
   const std::vector<std::shared_ptr<DiagGmm>>& pdfs() const { return pdfs_; }
+  // changes whenever a parameter of any pdf, or the list of pdfs, may have changed (get_pdf(i) hands out references: the pdfs
+  // carry their own versions)
+  uint64_t Version() const;
+  // The model on the device, uploaded when first asked for and again only after Version() moved: the reference's scripts pass the
+  // same AmDiagGmm to gmm_align_compiled / gmm_acc_stats_ali once per utterance (egs/yesno/train.py:170-202).
+  khg_model* DeviceModel(khg_ctx* ctx) const;
+  void DropDeviceModel() const { std::lock_guard<std::mutex> lk(dev_->mu); dev_->Release(); }
 
  private:
+  struct Dev {
+    std::mutex mu; khg_ctx* ctx = nullptr; khg_model* h = nullptr; uint64_t version = 0;
+    void Release() { if (h) khg_model_destroy(h); h = nullptr; }
+    ~Dev() { Release(); }
+  };
   std::vector<std::shared_ptr<DiagGmm>> pdfs_;
+  uint64_t struct_version_ = NextVersion();
+  std::shared_ptr<Dev> dev_ = std::make_shared<Dev>();     // per object: CopyFromAmDiagGmm copies the pdfs, not the handle
 };
 
 // ---- csrc/mle-diag-gmm.h:23-45 -----------------------------------------------------------------------------------------
@@ -233,17 +258,22 @@ float MlObjective(const DiagGmm& gmm, const AccumDiagGmm& acc);   // :479-499
 std::pair<float, float> MapDiagGmmUpdate(const MapDiagGmmOptions& cfg, const AccumDiagGmm& acc, int flags, DiagGmm* gmm);
 
 // ---- csrc/mle-am-diag-gmm.h:18-97 --------------------------------------------------------------------------------------
+class TransitionModel;
 class AccumAmDiagGmm {
  public:
+  AccumAmDiagGmm() = default;
+  AccumAmDiagGmm(const AccumAmDiagGmm& o) { *this = o; }
+  AccumAmDiagGmm& operator=(const AccumAmDiagGmm& o);          // deep copy of the host accumulators (the source's device sums flushed first)
   void Init(const AmDiagGmm& model, int dim /* <= 0: the model's */, int flags);
-  void SetZero(int flags) { for (auto& a : accs_) a->SetZero(flags); }
+  void SetZero(int flags) { DropDevice(); for (auto& a : accs_) a->SetZero(flags); }
   int NumAccs() const { return (int)accs_.size(); }
   int Dim() const { return accs_.empty() ? 0 : accs_[0]->Dim(); }
   float TotStatsCount() const;
-  float TotCount() const { return (float)total_frames_; }          // csrc/mle-am-diag-gmm.h:75
-  float TotLogLike() const { return (float)total_log_like_; }      // :76
+  float TotCount() const { Flush(); return (float)total_frames_; }          // csrc/mle-am-diag-gmm.h:75
+  float TotLogLike() const { Flush(); return (float)total_log_like_; }      // :76
   const std::shared_ptr<AccumDiagGmm>& Acc(int i) const {
     KHG_REQUIRE(i >= 0 && i < (int)accs_.size(), "index >= 0 && index < NumAccs() assertion failed");
+    Flush();
     return accs_[i];
   }
   float AccumulateForGmm(const AmDiagGmm& model, const float* data, size_t n, int gmm_index, float weight);   // .cc:41-52
@@ -256,13 +286,36 @@ class AccumAmDiagGmm {
   // a downloaded device block (after any all-reduce) added into these accumulators
   void AddDeviceStats(const int32_t* gauss_off, const double* occ, const double* mean, const double* var, int D, double total_frames,
                       double total_log_like);
-  std::vector<std::shared_ptr<AccumDiagGmm>>& accs() { return accs_; }
-  const std::vector<std::shared_ptr<AccumDiagGmm>>& accs() const { return accs_; }
-  double total_frames_ = 0.0, total_log_like_ = 0.0;
+  std::vector<std::shared_ptr<AccumDiagGmm>>& accs() { Flush(); return accs_; }
+  const std::vector<std::shared_ptr<AccumDiagGmm>>& accs() const { Flush(); return accs_; }
+  double total_frames() const { Flush(); return total_frames_; }
+  double total_log_like() const { Flush(); return total_log_like_; }
+  void set_total_frames(double v) { Flush(); total_frames_ = v; }
+  void set_total_log_like(double v) { Flush(); total_log_like_ = v; }
+
+  // scripts/gmm_acc_stats_ali.py:46-58 for one utterance (or several, concatenated): K3 over (feats, ali) into statistics that STAY
+  // ON THE DEVICE between calls -- the reference's caller invokes this once per utterance (egs/yesno/train.py:191-202), and a
+  // 207 MB block (5000 x 64 x 40) cannot cross PCIe per call.  Every host-side reader above first adds the pending device sums into
+  // the host accumulators (Flush: one download per EM pass).  -> the log-likelihood of these frames (tot_like_this_file).
+  double AccumulateAli(const AmDiagGmm& model, const TransitionModel& tm, const float* feats, const int64_t* frame_off, int n_utt, const int32_t* ali,
+                       float weight = 1.0f);
+  bool HasDeviceStats() const { return dev_ && dev_->pending; }
+  void Flush() const;        // pending device sums -> host accumulators (then the device block is zero again)
 
  private:
   void Chk(int i) const { KHG_REQUIRE(i >= 0 && i < (int)accs_.size(), "gmm_index >= 0 && gmm_index < NumAccs() assertion failed"); }
-  std::vector<std::shared_ptr<AccumDiagGmm>> accs_;
+  void DropDevice() const { dev_.reset(); }                    // pending device sums are DISCARDED (Init / SetZero)
+  struct Dev {
+    khg_ctx* ctx = nullptr; khg_accs* h = nullptr;
+    uint64_t model_version = 0; int num_tids = 0, D = 0;
+    std::vector<int32_t> gauss_off;
+    double seen_frames = 0.0, seen_ll = 0.0;                   // the block's running totals at the last call (a call's own log-like = the difference)
+    bool pending = false;
+    ~Dev() { if (h) khg_accs_destroy(h); }
+  };
+  mutable std::vector<std::shared_ptr<AccumDiagGmm>> accs_;
+  mutable double total_frames_ = 0.0, total_log_like_ = 0.0;
+  mutable std::shared_ptr<Dev> dev_;
 };
 
 // csrc/mle-am-diag-gmm.cc:153-202 -> (objf_change, count); am_gmm updated in place

@@ -466,4 +466,15 @@ bool GetPdfsForPhones(const TransitionModel& tm, const std::vector<int>& phones,
   return ok;
 }
 
+khg_tm* TransitionModel::DeviceTm(khg_ctx* ctx) const {
+  if (!dev_) dev_ = std::make_shared<Dev>();
+  std::lock_guard<std::mutex> lk(dev_->mu);
+  if (dev_->h && dev_->ctx == ctx && dev_->id2pdf == id2pdf_) return dev_->h;
+  if (dev_->h) { khg_tm_destroy(dev_->h); dev_->h = nullptr; }
+  std::vector<int32_t> t(id2pdf_.begin(), id2pdf_.end());
+  CApi(khg_tm_create(ctx, NumTransitionIds(), t.data(), &dev_->h));
+  dev_->ctx = ctx; dev_->id2pdf = id2pdf_;
+  return dev_->h;
+}
+
 }  // namespace khg

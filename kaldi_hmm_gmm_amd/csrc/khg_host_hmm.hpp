@@ -130,8 +130,16 @@ class TransitionModel : public TransitionInformation {
   std::vector<uint8_t> IsSelfLoopArray() const;
   std::vector<float> ScaledTransCost(float transition_scale, float self_loop_scale) const;     // csrc/hmm-utils.cc:442-463, negated
   std::string ToString() const;                                                                // csrc/transition-model.cc:37-83 text Write
+  // TransitionIdToPdf on the device (khg_tm), made when first asked for and again only when the table differs: the scripts pass the
+  // same TransitionModel to every per-utterance call
+  khg_tm* DeviceTm(khg_ctx* ctx) const;
 
  private:
+  struct Dev {
+    std::mutex mu; khg_ctx* ctx = nullptr; khg_tm* h = nullptr; std::vector<int> id2pdf;
+    ~Dev() { if (h) khg_tm_destroy(h); }
+  };
+  mutable std::shared_ptr<Dev> dev_;
   void ComputeTuplesIsHmm(const std::vector<std::vector<std::pair<int, int>>>& pdf_info);
   void ComputeDerived();
   void InitializeProbs();

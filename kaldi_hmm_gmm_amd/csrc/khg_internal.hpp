@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -32,6 +33,19 @@ int khg_set_error(int code, const std::string& msg);      // khg_ctx_model.hip; 
   } while (0)
 
 struct khg_timing { std::string name; hipEvent_t e0, e1; };
+// Scratch of the SMALL utterance sets (one call of the reference's per-utterance API = one set of one utterance: create, K1 + K2 or
+// K3, destroy): one device block mirrored by one pinned host block of the same size.  Allocation bumps a pointer (no hipMalloc /
+// hipFree per call), an upload is a memcpy into the mirror at the allocation's own offset -- all uploads staged since the last
+// launch go to the device in one copy per run of neighbouring allocations (arena_flush) --, a download lands in the mirror.  The block rewinds when its last live
+// allocation is released.  Requests that do not fit fall back to hipMalloc.
+struct KhgArena {
+  char *dev = nullptr, *host = nullptr;
+  size_t cap = 0, top = 0, base = 0;          // base: bytes reserved for the context itself (the error word)
+  int live = 0;
+  std::vector<std::pair<size_t, size_t>> dirty;   // staged mirror ranges not yet copied to the device (neighbours merged)
+  bool owns(const void* p) const { return dev && (const char*)p >= dev && (const char*)p < dev + cap; }
+  char* mirror(const void* dev_ptr) const { return host + ((const char*)dev_ptr - dev); }
+};
 struct khg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -42,15 +56,25 @@ struct khg_ctx {
   hipEvent_t ev_k3 = nullptr, ev_c1 = nullptr;
   bool own_stream = false;
   int32_t* err_flag_d = nullptr;
+  int32_t* err_host = nullptr;      // 256 pinned bytes: [0] landing word of check_err_flag, [64..128) the 8 scalars of khg_accs_download_trans
+  bool side_dirty[NSIDE] = {false, false, false, false};   // work was enqueued on the side stream since it was last waited for
   float* dump_d = nullptr;          // 256 floats nobody reads (K1 f16x2s: where the pipeline's first, empty value goes)
+  KhgArena arena;
+  bool pageable_pending = false;    // a hipMemcpyAsync from pageable host memory may still be reading its source (sync_pageable)
   bool timing = false;
   std::vector<khg_timing> timings;
   int opt[KHG_OPT_COUNT] = {};    // khg_ctx_set_option (KHG_OPT_*); the environment variables of include/khg_hip.h only seed the defaults, once, at khg_ctx_create
 };
-// scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled)
+int arena_flush(khg_ctx* ctx);                             // khg_ctx_model.hip: staged uploads -> device, one copy on the context's stream
+void* arena_alloc(khg_ctx* ctx, size_t bytes);             // 256-byte aligned; NULL when the block is full (or could not be made)
+bool khg_arena_release(void* p);                           // true when p came from some context's arena
+void khg_dev_free(void* p);                                // arena or hipFree
+void arena_mark_dirty(khg_ctx* ctx, const void* dev_ptr, size_t bytes);
+// scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled); staged uploads go out first
 struct KernelTimer {
   khg_ctx* c; size_t idx = 0; bool on; hipStream_t s;
   KernelTimer(khg_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx), on(ctx->timing), s(st ? st : ctx->stream) {
+    (void)arena_flush(ctx);
     if (!on) return;
     khg_timing t; t.name = name;
     (void)hipEventCreate(&t.e0); (void)hipEventCreate(&t.e1);
@@ -71,10 +95,17 @@ template <class T>
 inline int dev_upload(khg_ctx* ctx, T** p, const std::vector<T>& v) {
   int rc = dev_alloc(p, v.size());
   if (rc) return rc;
-  if (!v.empty()) HIPCHK(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  if (!v.empty()) { HIPCHK(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream)); ctx->pageable_pending = true; }
   return KHG_OK;
 }
-#define DEVFREE(p) do { if (p) { (void)hipFree((void*)(p)); (p) = nullptr; } } while (0)
+// after uploads from host vectors that are about to go out of scope: waits only if a pageable copy was issued since the last wait
+inline int sync_pageable(khg_ctx* ctx) {
+  if (!ctx->pageable_pending) return KHG_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->pageable_pending = false;
+  return KHG_OK;
+}
+#define DEVFREE(p) do { if (p) { khg_dev_free((void*)(p)); (p) = nullptr; } } while (0)
 
 // kernel-side plan / result records the handles only hold pointers to (defined beside their kernels, khg_k*.hip.inc)
 struct KwChunk; struct K1Chunk; struct K1pEntry; struct K1pSlice; struct K1bChunk; struct K1sChunk; struct K1sUnit; struct K4Res;
@@ -119,6 +150,8 @@ struct ImgSync {
 // ------------------------------------------------------------------------------------------
 struct khg_model {
   khg_ctx* ctx = nullptr;
+  uint64_t serial = 0;       // unique per handle: khg_model_lookup(serial) tells a live handle from a destroyed one (or its address reused)
+  uint64_t version = 0;      // bumped whenever the parameters or their layout change in place (model_pack)
   int32_t P = 0, D = 0, KQ = 0, ntiles = 0;
   int64_t sumG = 0;
   std::vector<int32_t> gauss_off, pdf_tile_off;
@@ -168,6 +201,7 @@ struct khg_tm {
 
 struct khg_utts {
   khg_ctx* ctx = nullptr;
+  bool small = false;            // scratch from the context's arena (KhgArena): few utterances, one call each
   int32_t n_utt = 0, D = 0;
   int64_t N = 0;  // total frames
   bool has_graphs = false;
@@ -194,7 +228,7 @@ struct khg_utts {
   // BAND form of the default K1 (khg_loglikes_band): what khg_align needs to recompute the utterances whose beam certificate fails
   int ll_mode = 0;                 // how the resident scores were computed: 0 every cell, 1 from the first needed tile, 2 band
   void* band_args = nullptr;       // K1sArgs of the band launch (khg_k1.hip owns it)
-  khg_model* band_model = nullptr; int band_ks = 0; size_t band_lds = 0;
+  khg_model* band_model = nullptr; int band_ks = 0; size_t band_lds = 0; uint64_t band_serial = 0, band_version = 0; std::vector<int32_t> band_key;   // ... and which model / parameter version / fp16 image they belong to int band_ks = 0; size_t band_lds = 0;
   int tiles_reach = -1;            // whether the walk lists carry those first frames (reachable-only K1) or zeros
   std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
   int64_t* tile2_off_d = nullptr; int32_t* tiles2_d = nullptr; std::vector<int32_t> tiles2_pto; int tiles2_reach = -1;   // bf16x3: pair walk
@@ -224,6 +258,7 @@ struct khg_utts {
   int32_t *ali_d = nullptr, *words_d = nullptr, *num_words_d = nullptr, *status_d = nullptr;
   float* like_d = nullptr;
   bool ali_valid = false;
+  char* out_blk_d = nullptr; size_t out_blk_bytes = 0;   // small sets: [status | like | num_words | words | ali] in one arena block = one download
   hipEvent_t ev_dp = nullptr, ev_ali = nullptr;   // K2-DP done (main) -> faithful kernel (side) -> alignment complete
   bool ali_pending = false;
   // K3 scratch
@@ -249,12 +284,37 @@ struct khg_accs {
   double* scalars() const { return trans() + num_tids + 1; }
 };
 
+// allocations / uploads owned by an utterance set: the context's arena for small sets, hipMalloc otherwise
+constexpr size_t KHG_ARENA_MAX_REQ = size_t(4) << 20;
+template <class T>
+inline int u_alloc(khg_utts* u, T** p, size_t n) {
+  if (n == 0) n = 1;
+  if (u->small && n * sizeof(T) <= KHG_ARENA_MAX_REQ) {
+    *p = static_cast<T*>(arena_alloc(u->ctx, n * sizeof(T)));
+    if (*p) return KHG_OK;
+  }
+  return dev_alloc(p, n);
+}
+template <class T>
+inline int u_upload(khg_ctx* ctx, khg_utts* u, T** p, const std::vector<T>& v) {
+  if (u->small && v.size() * sizeof(T) <= KHG_ARENA_MAX_REQ) {
+    *p = static_cast<T*>(arena_alloc(u->ctx, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (*p) {
+      if (!v.empty()) { memcpy(u->ctx->arena.mirror(*p), v.data(), v.size() * sizeof(T)); arena_mark_dirty(u->ctx, *p, v.size() * sizeof(T)); }
+      return KHG_OK;
+    }
+  }
+  return dev_upload(ctx, p, v);
+}
+
 // ---- functions one unit calls in another ---------------------------------------------------------------------------------
 int check_err_flag(khg_ctx* c, const char* where);        // khg_ctx_model.hip: read-and-clear the device error word (synchronises)
 int model_pack(khg_ctx* ctx, khg_model* m);               // khg_ctx_model.hip: everything derived from gauss_off + the row-major parameters
 int wait_ali(khg_ctx* ctx, khg_utts* u);                  // khg_utts.hip: the main stream waits for the side-stream decoder
 void k1_free_band(khg_utts* u);                           // khg_k1.hip: the BAND form's saved launch arguments
 int k1_maxima(khg_ctx* ctx, khg_model* m, khg_utts* u, std::vector<float>* xk);   // khg_k1.hip: column maxima of features / parameters
+khg_model* khg_model_lookup(uint64_t serial);             // khg_ctx_model.hip: the live handle with this serial, or NULL
+int k1_band_check(khg_ctx* ctx, khg_utts* u);             // khg_k1.hip: the band's model is alive and unchanged (re-scores when only its image was re-packed)
 int k1_band_repair(khg_ctx* ctx, khg_utts* u, int32_t* status_d, int repair_bit, hipStream_t side);   // khg_k1.hip
 int accs_allreduce_pieces(khg_ctx* ctx, khg_accs* a, const khg_model* m, int first_pdf, int n_pdf, void* comm, hipStream_t st);   // khg_c1.hip
 int ctx_comm_stream(khg_ctx* ctx);                        // khg_c1.hip

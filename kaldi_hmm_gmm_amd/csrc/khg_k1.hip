@@ -30,9 +30,9 @@ static int loglikes_wide(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
       for (int64_t t0 = 0; t0 < T; t0 += 64) ch.push_back(KwChunk{i, (int32_t)t0, (int32_t)std::min<int64_t>(64, T - t0), 0});
     }
     u->n_wchunks = (int)ch.size();
-    int rc = dev_upload(ctx, &u->wchunks_d, ch);
+    int rc = u_upload(ctx, u, &u->wchunks_d, ch);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rs = sync_pageable(ctx); if (rs) return rs; }
   }
   KwArgs a;
   a.feats = u->feats_d; a.frame_off = u->frame_off_d; a.chunks = u->wchunks_d; a.pdf_off = u->pdf_off_d; a.pdfs = u->pdfs_d;
@@ -62,9 +62,9 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     for (int i = 0; i < u->n_utt; ++i)
       for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
     int32_t* xutt_d = nullptr;
-    rc = dev_upload(ctx, &u->utt_xtile_off_d, xoff);
+    rc = u_upload(ctx, u, &u->utt_xtile_off_d, xoff);
     if (!rc) rc = dev_upload(ctx, &xutt_d, xutt);
-    if (!rc) rc = dev_alloc(&u->xpl_d, (size_t)std::max<int64_t>(nx, 1) * 2 * 16 * KH);
+    if (!rc) rc = u_alloc(u, &u->xpl_d, (size_t)std::max<int64_t>(nx, 1) * 2 * 16 * KH);
     if (!rc && nx > 0) {
       const int gb = (int)std::min<int64_t>(65535, (nx * (2 * 16 * KH / 4) + 255) / 256);
       if (m->KQ == 10) hipLaunchKernelGGL(k1p_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
@@ -124,10 +124,10 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     for (int k = 0; k < 10; ++k) u->p_grp[k] = 0;
     for (const auto& s : slices) u->p_grp[nblk_of(s)]++;          // counts per block count 1..4
     if (ents.size() >= (size_t)INT32_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: too many (utterance, pdf) entries");
-    rc = dev_upload(ctx, &u->p_ents_d, ents);
-    if (!rc) rc = dev_upload(ctx, &u->p_slices_d, slices);
+    rc = u_upload(ctx, u, &u->p_ents_d, ents);
+    if (!rc) rc = u_upload(ctx, u, &u->p_slices_d, slices);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rs = sync_pageable(ctx); if (rs) return rs; }
     u->p_nslices = (int32_t)slices.size();
     if (ctx->opt[KHG_OPT_DEBUG]) { long long tt = 0; for (auto& s : slices) tt += s.ntiles; fprintf(stderr, "[khg] pdf-major plan: %zu entries, %zu slices, %lld tiles\n", ents.size(), slices.size(), tt); }
     u->p_reach = (int)reachable_only;
@@ -182,10 +182,10 @@ static int ensure_walk(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reach
     }
     toff[(size_t)i + 1] = (int64_t)tiles.size();
   }
-  int rc = dev_upload(ctx, &u->tile_off_d, toff);
-  if (!rc) rc = dev_upload(ctx, &u->tiles_d, tiles);
+  int rc = u_upload(ctx, u, &u->tile_off_d, toff);
+  if (!rc) rc = u_upload(ctx, u, &u->tiles_d, tiles);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rs = sync_pageable(ctx); if (rs) return rs; }
   u->tiles_pto = m->pdf_tile_off;
   u->tiles_reach = (int)reachable_only;
   return KHG_OK;
@@ -200,10 +200,10 @@ static int ensure_x32_layout(khg_ctx* ctx, khg_utts* u) {
   std::vector<int32_t> xutt((size_t)nx);
   for (int i = 0; i < u->n_utt; ++i)
     for (int64_t t = xoff[(size_t)i]; t < xoff[(size_t)i + 1]; ++t) xutt[(size_t)t] = i;
-  int rc = dev_upload(ctx, &u->utt_x32_off_d, xoff);
-  if (!rc) rc = dev_upload(ctx, &u->x32_utt_d, xutt);
+  int rc = u_upload(ctx, u, &u->utt_x32_off_d, xoff);
+  if (!rc) rc = u_upload(ctx, u, &u->x32_utt_d, xutt);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rs = sync_pageable(ctx); if (rs) return rs; }
   u->n_x32 = nx;
   return KHG_OK;
 }
@@ -235,9 +235,9 @@ static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
   DEVFREE(u->bchunks_d);
   std::vector<K1bChunk> ch;
   plan_x32_chunks(u, 8 * NTMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
-  rc = dev_upload(ctx, &u->bchunks_d, ch);
+  rc = u_upload(ctx, u, &u->bchunks_d, ch);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rs = sync_pageable(ctx); if (rs) return rs; }
   u->n_bchunks = (int32_t)ch.size(); u->bchunk_nt = NTMAX;
   return KHG_OK;
 }
@@ -268,7 +268,7 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool 
   if (!u->xb3_d || u->xb3_ks != KS) {
     DEVFREE(u->xb3_d);
     const int64_t nx = u->n_x32;
-    rc = dev_alloc(&u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
+    rc = u_alloc(u, &u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
     if (!rc && nx > 0) {
       const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
       if (KS == 5) hipLaunchKernelGGL(k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
@@ -398,11 +398,11 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
     const int64_t nx = u->n_x32;
     if (!u->xh_d || u->xh_ks != KS) {
       DEVFREE(u->xh_d);
-      rc = dev_alloc(&u->xh_d, (size_t)std::max<int64_t>(nx, 1) * 2 * KS * 64);
+      rc = u_alloc(u, &u->xh_d, (size_t)std::max<int64_t>(nx, 1) * 2 * KS * 64);
       if (rc) return rc;
     }
     DEVFREE(u->xh_ex_d);
-    rc = dev_upload(ctx, &u->xh_ex_d, ex);
+    rc = u_upload(ctx, u, &u->xh_ex_d, ex);
     if (rc) return rc;
     if (nx > 0) {
       KernelTimer kt(ctx, "k1h_pack_x");
@@ -411,7 +411,7 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
       else hipLaunchKernelGGL(k1h_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
       HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));    // `ex` (pageable) is free after this
+    { int rs = sync_pageable(ctx); if (rs) return rs; }    // `ex` (pageable) is free after this
     u->xh_ks = KS; u->xh_ex = ex;
   }
   if (m->wimgh_ex != u->xh_ex) {
@@ -522,10 +522,12 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
   if (!u->schunks_d || u->schunk_nmax != NMAX) {
     DEVFREE(u->schunks_d);
     std::vector<K1sChunk> ch;
-    plan_x32_chunks(u, NMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
-    rc = dev_upload(ctx, &u->schunks_d, ch);
+    // (a set of a few utterances cannot fill the chip with whole utterances: short chunks spread it over more workgroups -- the W
+    //  tiles are re-read per chunk from the cache, a band that crosses chunks keeps its aligned tiles)
+    plan_x32_chunks(u, u->small ? std::min(NMAX, 3) : NMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
+    rc = u_upload(ctx, u, &u->schunks_d, ch);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rs = sync_pageable(ctx); if (rs) return rs; }
     u->n_schunks = (int32_t)ch.size(); u->schunk_nmax = NMAX;
   }
   // the set's B fragments: packed once (the exponents depend on the features alone)
@@ -533,11 +535,11 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     const int64_t nx = u->n_x32;
     if (!u->xs_d || u->xs_ks != KS) {
       DEVFREE(u->xs_d);
-      rc = dev_alloc(&u->xs_d, (size_t)std::max<int64_t>(nx, 1) * 2 * KS * 64);
+      rc = u_alloc(u, &u->xs_d, (size_t)std::max<int64_t>(nx, 1) * 2 * KS * 64);
       if (rc) return rc;
     }
     DEVFREE(u->xs_ex_d);
-    rc = dev_upload(ctx, &u->xs_ex_d, ex);
+    rc = u_upload(ctx, u, &u->xs_ex_d, ex);
     if (rc) return rc;
     if (nx > 0) {
       KernelTimer kt(ctx, "k1s_pack_x");
@@ -546,7 +548,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
       else hipLaunchKernelGGL(k1s_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
       HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));    // `ex` (pageable) is free after this
+    { int rs = sync_pageable(ctx); if (rs) return rs; }    // `ex` (pageable) is free after this
     u->xs_ks = KS; u->xs_ex = ex;
   }
   // the model's image for these exponents
@@ -618,9 +620,9 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
       }
       units[k] = K1sUnit{m->pdf_tile_off[p], (uint32_t)nt | (shift << 11) | (need << 16) | (last << 24)};
     }
-    rc = dev_upload(ctx, &u->sunits_d, units);
+    rc = u_upload(ctx, u, &u->sunits_d, units);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rs = sync_pageable(ctx); if (rs) return rs; }
     u->sunits_pto = m->pdf_tile_off;
     u->sunits_reach = units_key;
   }
@@ -652,6 +654,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     if (band) {
       if (!u->band_args) u->band_args = new K1sArgs();
       *static_cast<K1sArgs*>(u->band_args) = a; u->band_model = m; u->band_ks = KS; u->band_lds = lds;
+      u->band_serial = m->serial; u->band_version = m->version; u->band_key = m->wimgs_key;
     }
     const void* fn = pack == 4 ? (const void*)k1s_loglikes_packed<5, 4> : pack == 2 ? (const void*)k1s_loglikes_packed<5, 2>
                      : KS == 5 ? (const void*)k1s_loglikes<5> : (const void*)k1s_loglikes<10>;
@@ -685,10 +688,10 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reac
   int rc = wait_ali(ctx, u);
   if (rc) return rc;
   if (!u->pdf_off_d) {
-    rc = dev_upload(ctx, &u->pdf_off_d, u->pdf_off);
-    if (!rc) rc = dev_upload(ctx, &u->pdfs_d, u->pdfs);
-    if (!rc) rc = dev_upload(ctx, &u->ll_off_d, u->ll_off);
-    if (!rc) rc = dev_alloc(&u->ll_d, (size_t)u->ll_total);
+    rc = u_upload(ctx, u, &u->pdf_off_d, u->pdf_off);
+    if (!rc) rc = u_upload(ctx, u, &u->pdfs_d, u->pdfs);
+    if (!rc) rc = u_upload(ctx, u, &u->ll_off_d, u->ll_off);
+    if (!rc) rc = u_alloc(u, &u->ll_d, (size_t)u->ll_total);
     if (rc) return rc;
   }
   {
@@ -738,9 +741,9 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reac
     }
     u->n_chunks = (int)ch.size();
     u->chunk_kq = m->KQ * 16 + k1_nf(ctx, m->KQ);
-    rc = dev_upload(ctx, &u->chunks_d, ch);
+    rc = u_upload(ctx, u, &u->chunks_d, ch);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // ch is a local
+    { int rs = sync_pageable(ctx); if (rs) return rs; }  // ch is a local
   }
   rc = ensure_walk(ctx, m, u, reachable_only);
   if (rc) return rc;
@@ -796,16 +799,31 @@ extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
   int rc = wait_ali(ctx, u);
   if (rc) return rc;
   if (!u->pdf_off_d) {
-    rc = dev_upload(ctx, &u->pdf_off_d, u->pdf_off);
-    if (!rc) rc = dev_upload(ctx, &u->pdfs_d, u->pdfs);
-    if (!rc) rc = dev_upload(ctx, &u->ll_off_d, u->ll_off);
-    if (!rc) rc = dev_alloc(&u->ll_d, (size_t)u->ll_total);
+    rc = u_upload(ctx, u, &u->pdf_off_d, u->pdf_off);
+    if (!rc) rc = u_upload(ctx, u, &u->pdfs_d, u->pdfs);
+    if (!rc) rc = u_upload(ctx, u, &u->ll_off_d, u->ll_off);
+    if (!rc) rc = u_alloc(u, &u->ll_d, (size_t)u->ll_total);
     if (rc) return rc;
   }
   HIPCHK(hipMemcpyAsync(u->ll_d, ll, sizeof(float) * (size_t)u->ll_total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   u->ll_mode = 0; u->band_model = nullptr;      // the caller's scores: every cell as given
   u->ll_valid = true;
+  return KHG_OK;
+}
+
+// BAND form: khg_align's repair launch reads the model the scores were computed with -- its fp16 image, its upper bounds -- through
+// pointers saved at khg_loglikes_band.  Before anything is launched: that handle must still be alive (by serial, not by address) and
+// at the same parameter version; and if only its IMAGE was re-packed since (another set lowered the shared feature exponents), this
+// set's planes no longer match it: the set is scored again, in the band form, against the current image.
+int k1_band_check(khg_ctx* ctx, khg_utts* u) {
+  if (u->ll_mode != 2 || !u->band_args) return KHG_OK;
+  khg_model* bm = khg_model_lookup(u->band_serial);
+  if (!bm || bm != u->band_model || bm->version != u->band_version) {
+    u->ll_valid = false;
+    return khg_set_error(KHG_E_ARG, "khg_align: the model these scores were computed with (khg_loglikes_band) was destroyed or updated since; call khg_loglikes_band again");
+  }
+  if (bm->wimgs_key != u->band_key) return loglikes_impl(ctx, bm, u, 2);
   return KHG_OK;
 }
 

@@ -12,9 +12,21 @@ extern "C" void khg_align_config_default(khg_align_config* c) {
   c->like_scale = 0.0f;
 }
 
+// The resident alignment.  Small sets with graphs keep everything khg_align hands back -- [status | like | num_words | words | ali] --
+// in ONE block (of the context's arena: one download into its pinned mirror instead of five pageable copies).
 static int ensure_ali(khg_ctx* ctx, khg_utts* u) {
-  if (!u->ali_d) { int rc = dev_alloc(&u->ali_d, (size_t)u->N); if (rc) return rc; }
-  return KHG_OK;
+  if (u->ali_d) return KHG_OK;
+  if (u->small && u->has_graphs) {
+    const size_t nu = (size_t)u->n_utt, nw = (size_t)u->words_off[u->n_utt];
+    const size_t bytes = 4 * (3 * nu + nw + (size_t)u->N) + 64;
+    int rc = u_alloc(u, &u->out_blk_d, bytes);
+    if (rc) return rc;
+    u->out_blk_bytes = bytes;
+    int32_t* p = reinterpret_cast<int32_t*>(u->out_blk_d);
+    u->status_d = p; u->like_d = reinterpret_cast<float*>(p + nu); u->num_words_d = p + 2 * nu; u->words_d = p + 3 * nu; u->ali_d = p + 3 * nu + nw;
+    return KHG_OK;
+  }
+  return u_alloc(u, &u->ali_d, (size_t)u->N);
 }
 
 extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_align_config* cfg,
@@ -30,17 +42,20 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   if (!(cfg->hash_ratio >= 1.0) || !(cfg->max_active > 1) || !(cfg->min_active >= 0 && cfg->min_active < cfg->max_active))
     return khg_set_error(KHG_E_RUNTIME, "FasterDecoderOptions assertion failed");
   int rc = wait_ali(ctx, u);
+  if (!rc) rc = k1_band_check(ctx, u);      // BAND scores: their model must be alive and unchanged (khg_k1.hip)
   if (!rc) rc = ensure_ali(ctx, u);
   if (rc) return rc;
   if (!u->bp_d) {
-    rc = dev_alloc(&u->bp_d, (size_t)u->bp_off[u->n_utt]);
-    if (!rc) rc = dev_alloc(&u->layer_best_d, (size_t)(u->N + u->n_utt));
-    if (!rc) rc = dev_alloc(&u->layer_cnt_d, (size_t)(u->N + u->n_utt));
-    if (!rc) rc = dev_alloc(&u->path_d, (size_t)u->path_off[u->n_utt]);
-    if (!rc) rc = dev_alloc(&u->words_d, (size_t)u->words_off[u->n_utt]);
-    if (!rc) rc = dev_alloc(&u->num_words_d, (size_t)u->n_utt);
-    if (!rc) rc = dev_alloc(&u->status_d, (size_t)u->n_utt);
-    if (!rc) rc = dev_alloc(&u->like_d, (size_t)u->n_utt);
+    rc = u_alloc(u, &u->bp_d, (size_t)u->bp_off[u->n_utt]);
+    if (!rc) rc = u_alloc(u, &u->layer_best_d, (size_t)(u->N + u->n_utt));
+    if (!rc) rc = u_alloc(u, &u->layer_cnt_d, (size_t)(u->N + u->n_utt));
+    if (!rc) rc = u_alloc(u, &u->path_d, (size_t)u->path_off[u->n_utt]);
+    if (!rc && !u->out_blk_d) {
+      rc = u_alloc(u, &u->words_d, (size_t)u->words_off[u->n_utt]);
+      if (!rc) rc = u_alloc(u, &u->num_words_d, (size_t)u->n_utt);
+      if (!rc) rc = u_alloc(u, &u->status_d, (size_t)u->n_utt);
+      if (!rc) rc = u_alloc(u, &u->like_d, (size_t)u->n_utt);
+    }
     if (rc) return rc;
   }
   HIPCHK(hipMemsetAsync(u->ali_d, 0, sizeof(int32_t) * (size_t)u->N, ctx->stream));
@@ -56,15 +71,15 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   a.like = u->like_d; a.status = u->status_d; a.err_flag = ctx->err_flag_d;
   a.prof = nullptr;
   // launch order of the DP kernel: longest utterances first (built once per set)
-  if (!u->k2_order_d && u->n_utt > 0) {
+  if (!u->k2_order_d && u->n_utt > 1) {
     std::vector<int32_t> ord((size_t)u->n_utt);
     for (int i = 0; i < u->n_utt; ++i) ord[(size_t)i] = i;
     std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
       return u->frame_off[x + 1] - u->frame_off[x] > u->frame_off[y + 1] - u->frame_off[y];
     });
-    int rc2 = dev_upload(ctx, &u->k2_order_d, ord);
+    int rc2 = u_upload(ctx, u, &u->k2_order_d, ord);
+    if (!rc2) rc2 = sync_pageable(ctx);
     if (rc2) return rc2;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   a.order = ctx->opt[KHG_OPT_K2_INORDER] ? nullptr : u->k2_order_d;
   const bool k2prof = ctx->opt[KHG_OPT_K2_PROF] != 0;
@@ -119,7 +134,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     const size_t need = stride * (size_t)u->n_utt;
     if (need > u->k2_gscratch_bytes) {
       DEVFREE(u->k2_gscratch_d);
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&u->k2_gscratch_d), need));
+      { int rg = u_alloc(u, &u->k2_gscratch_d, need); if (rg) return rg; }
       u->k2_gscratch_bytes = need;
     }
     a.gscratch = u->k2_gscratch_d; a.gscratch_stride = (int64_t)stride;
@@ -161,11 +176,19 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
 #undef K2_DP_CASES
   }
   HIPCHK(hipGetLastError());
-  if (!u->ev_dp) { HIPCHK(hipEventCreateWithFlags(&u->ev_dp, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&u->ev_ali, hipEventDisableTiming)); }
-  HIPCHK(hipEventRecord(u->ev_dp, ctx->stream));
-  hipStream_t side = ctx->sides[ctx->next_side];
-  ctx->next_side = (ctx->next_side + 1) % khg_ctx::NSIDE;
-  HIPCHK(hipStreamWaitEvent(side, u->ev_dp, 0));
+  // The order-faithful decoder for what the DP could not certify runs on a side stream, beside the main stream's next K1 -- unless
+  // the caller waits for the results right here (host outputs): then nothing can overlap it, and it follows the DP on the main
+  // stream without the two cross-stream events (the per-utterance call pattern: ~30 us of a ~300 us call).
+  const bool sync_call = ali_h || like_h || status_h || words_h;
+  hipStream_t side = ctx->stream;
+  if (!sync_call) {
+    if (!u->ev_dp) { HIPCHK(hipEventCreateWithFlags(&u->ev_dp, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&u->ev_ali, hipEventDisableTiming)); }
+    HIPCHK(hipEventRecord(u->ev_dp, ctx->stream));
+    side = ctx->sides[ctx->next_side];
+    ctx->side_dirty[ctx->next_side] = true;
+    ctx->next_side = (ctx->next_side + 1) % khg_ctx::NSIDE;
+    HIPCHK(hipStreamWaitEvent(side, u->ev_dp, 0));
+  }
   rc = k1_band_repair(ctx, u, u->status_d, K2_ST_NEED_FALLBACK, side);      // khg_k1.hip (BAND form of K1 only)
   if (rc) return rc;
   {
@@ -185,8 +208,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     }
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(u->ev_ali, side));
-  u->ali_pending = true;
+  if (!sync_call) { HIPCHK(hipEventRecord(u->ev_ali, side)); u->ali_pending = true; }
   u->ali_valid = true;
   if (k2prof) {  // diagnostics: average s_memtime ticks per phase of k2_viterbi_dp
     std::vector<long long> pr(8 * (size_t)u->n_utt);
@@ -201,6 +223,31 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   if (!ali_h && !like_h && !status_h && !words_h) return KHG_OK;   // asynchronous: errors surface at khg_ctx_sync / downloads
   rc = wait_ali(ctx, u);
   if (rc) return rc;
+  if (u->out_blk_d && ctx->arena.owns(u->out_blk_d)) {
+    // one block, one copy into its pinned mirror; the error word's own copy and wait follow it on the stream
+    char* hm = ctx->arena.mirror(u->out_blk_d);
+    HIPCHK(hipMemcpyAsync(hm, u->out_blk_d, u->out_blk_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    rc = check_err_flag(ctx, "khg_align");  // synchronises
+    if (rc) return rc;
+    const size_t nu = (size_t)u->n_utt, nwt = (size_t)u->words_off[u->n_utt];
+    const int32_t* hp = reinterpret_cast<const int32_t*>(hm);
+    if (status_h) memcpy(status_h, hp, 4 * nu);
+    if (like_h) memcpy(like_h, hp + nu, 4 * nu);
+    if (ali_h && u->N) memcpy(ali_h, hp + 3 * nu + nwt, 4 * (size_t)u->N);
+    if (words_h && words_off_h) {
+      const int32_t *nw = hp + 2 * nu, *w = hp + 3 * nu;
+      int64_t o = 0;
+      for (int i = 0; i < u->n_utt; ++i) {
+        words_off_h[i] = o;
+        const int64_t n = std::min<int64_t>(nw[i], u->words_off[i + 1] - u->words_off[i]);
+        if (o + n > words_cap) return khg_set_error(KHG_E_ARG, "khg_align: words_cap too small");
+        std::copy(w + u->words_off[i], w + u->words_off[i] + n, words_h + o);
+        o += n;
+      }
+      words_off_h[u->n_utt] = o;
+    }
+    return KHG_OK;
+  }
   rc = check_err_flag(ctx, "khg_align");  // synchronises
   if (rc) return rc;
   if (ali_h) HIPCHK(hipMemcpyAsync(ali_h, u->ali_d, sizeof(int32_t) * (size_t)u->N, hipMemcpyDeviceToHost, ctx->stream));
@@ -230,8 +277,12 @@ extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
   int rc = wait_ali(ctx, u);
   if (!rc) rc = ensure_ali(ctx, u);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(u->ali_d, ali, sizeof(int32_t) * (size_t)u->N, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->arena.owns(u->ali_d)) {          // staged: goes out with the next launch's flush
+    if (u->N) { memcpy(ctx->arena.mirror(u->ali_d), ali, sizeof(int32_t) * (size_t)u->N); arena_mark_dirty(ctx, u->ali_d, sizeof(int32_t) * (size_t)u->N); }
+  } else {
+    HIPCHK(hipMemcpyAsync(u->ali_d, ali, sizeof(int32_t) * (size_t)u->N, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   u->ali_valid = true;
   return KHG_OK;
 }

@@ -121,14 +121,15 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");
   if (tm->max_pdf >= m->P) return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: transition model refers to pdf-ids the model does not have");
   int rc = wait_ali(ctx, u);
+  if (!rc) rc = arena_flush(ctx);
   if (rc) return rc;
   if (!u->frame_ids_d || u->k3_P != m->P || u->k3_tids != tm->num_tids) {
     DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d); DEVFREE(u->frame_ids_d);
-    rc = dev_alloc(&u->pdf_count_d, (size_t)m->P);
-    if (!rc) rc = dev_alloc(&u->pdf_cursor_d, (size_t)m->P);
-    if (!rc) rc = dev_alloc(&u->pdf_start_d, (size_t)m->P + 1);
-    if (!rc) rc = dev_alloc(&u->tid_count_d, (size_t)tm->num_tids + 1);
-    if (!rc) rc = dev_alloc(&u->frame_ids_d, (size_t)u->N);
+    rc = u_alloc(u, &u->pdf_count_d, (size_t)m->P);
+    if (!rc) rc = u_alloc(u, &u->pdf_cursor_d, (size_t)m->P);
+    if (!rc) rc = u_alloc(u, &u->pdf_start_d, (size_t)m->P + 1);
+    if (!rc) rc = u_alloc(u, &u->tid_count_d, (size_t)tm->num_tids + 1);
+    if (!rc) rc = u_alloc(u, &u->frame_ids_d, (size_t)u->N);
     if (rc) return rc;
     u->k3_P = m->P; u->k3_tids = tm->num_tids;
   }
@@ -162,8 +163,8 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         while (CB > 64 * nw * 4 && (u->N + CB - 1) / CB < 1024) CB /= 2;   // enough blocks to fill the chip on small sets
         const int nblk = (int)((u->N + CB - 1) / CB);
         const size_t hist_n = (size_t)nblk * ((size_t)m->P + 1);
-        if (u->cs_hist_n < hist_n) { DEVFREE(u->cs_hist_d); rc = dev_alloc(&u->cs_hist_d, hist_n); if (rc) return rc; u->cs_hist_n = hist_n; }
-        if (u->cs_tot_n < (size_t)m->P + 1) { DEVFREE(u->cs_tot_d); rc = dev_alloc(&u->cs_tot_d, (size_t)m->P + 1); if (rc) return rc; u->cs_tot_n = (size_t)m->P + 1; }
+        if (u->cs_hist_n < hist_n) { DEVFREE(u->cs_hist_d); rc = u_alloc(u, &u->cs_hist_d, hist_n); if (rc) return rc; u->cs_hist_n = hist_n; }
+        if (u->cs_tot_n < (size_t)m->P + 1) { DEVFREE(u->cs_tot_d); rc = u_alloc(u, &u->cs_tot_d, (size_t)m->P + 1); if (rc) return rc; u->cs_tot_n = (size_t)m->P + 1; }
         K3CsArgs c{u->cs_hist_d, u->cs_tot_d, (int32_t)CB, nblk};
         const bool ldst = tm->num_tids <= K3_LDS_TIDS;
         const size_t lds_h = sizeof(unsigned int) * ((size_t)m->P + 1 + (ldst ? (size_t)tm->num_tids + 1 : 0));
@@ -184,9 +185,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         int bits = 1;
         while ((1 << bits) <= m->P) ++bits;            // keys are 0..P
         if (!u->sort_keys_d) {
-          rc = dev_alloc(&u->sort_keys_d, (size_t)u->N);
-          if (!rc) rc = dev_alloc(&u->sort_keys_out_d, (size_t)u->N);
-          if (!rc) rc = dev_alloc(&u->sort_vals_d, (size_t)u->N);
+          rc = u_alloc(u, &u->sort_keys_d, (size_t)u->N);
+          if (!rc) rc = u_alloc(u, &u->sort_keys_out_d, (size_t)u->N);
+          if (!rc) rc = u_alloc(u, &u->sort_vals_d, (size_t)u->N);
           if (rc) return rc;
         }
         size_t need = 0;
@@ -194,7 +195,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
                                                   reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
         if (need > u->sort_tmp_bytes) {
           DEVFREE(u->sort_tmp_d);
-          HIPCHK(hipMalloc(&u->sort_tmp_d, need));
+          { int rt = u_alloc(u, reinterpret_cast<char**>(&u->sort_tmp_d), need); if (rt) return rt; }
           u->sort_tmp_bytes = need;
         }
         if (tm->num_tids <= K3_LDS_TIDS) hipLaunchKernelGGL(k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
@@ -218,18 +219,18 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       if (max_items >= INT_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: too many work items");
       if (u->k3_items_n < (size_t)max_items) {
         DEVFREE(u->k3_items_d);
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&u->k3_items_d), sizeof(K3Item) * (size_t)max_items));
+        { int ri = u_alloc(u, reinterpret_cast<K3Item**>(&u->k3_items_d), (size_t)max_items); if (ri) return ri; }
         u->k3_items_n = (size_t)max_items;
       }
       if (u->k3_item_off_n < (size_t)m->P + 1) {
         DEVFREE(u->k3_item_off_d);
-        int rc2 = dev_alloc(&u->k3_item_off_d, (size_t)m->P + 1);
+        int rc2 = u_alloc(u, &u->k3_item_off_d, (size_t)m->P + 1);
         if (rc2) return rc2;
         u->k3_item_off_n = (size_t)m->P + 1;
       }
       if (parked && u->k3_part_n < (size_t)max_slots * nsum1) {
         DEVFREE(u->k3_part_d);
-        int rc2 = dev_alloc(&u->k3_part_d, (size_t)max_slots * nsum1);
+        int rc2 = u_alloc(u, &u->k3_part_d, (size_t)max_slots * nsum1);
         if (rc2) return rc2;
         u->k3_part_n = (size_t)max_slots * nsum1;
       }
@@ -272,7 +273,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       const size_t nsum1 = (size_t)nb * 16 * 80 + (size_t)nb * 16 + 1;
       if (u->k3_llpart_n < (size_t)m->P) {
         DEVFREE(u->k3_llpart_d);
-        rc = dev_alloc(&u->k3_llpart_d, (size_t)m->P);
+        rc = u_alloc(u, &u->k3_llpart_d, (size_t)m->P);
         if (rc) return rc;
         u->k3_llpart_n = (size_t)m->P;
       }

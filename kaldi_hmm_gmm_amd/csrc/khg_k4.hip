@@ -377,6 +377,14 @@ extern "C" int khg_accs_relayout(khg_ctx* ctx, khg_accs* a, const khg_model* m) 
 }
 extern "C" int khg_accs_download_trans(khg_ctx* ctx, const khg_accs* a, double* trans, double* scalars) {
   if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_download_trans: bad arguments");
+  if (!trans && scalars) {      // the per-utterance call pattern reads only the totals: one pinned copy in front of the error word's
+    double* land = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->err_host) + 64);
+    HIPCHK(hipMemcpyAsync(land, a->scalars(), sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = check_err_flag(ctx, "khg_acc_stats");
+    if (rc) return rc;
+    memcpy(scalars, land, sizeof(double) * 8);
+    return KHG_OK;
+  }
   { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
   if (trans) HIPCHK(hipMemcpyAsync(trans, a->trans(), sizeof(double) * ((size_t)a->num_tids + 1), hipMemcpyDeviceToHost, ctx->stream));
   if (scalars) HIPCHK(hipMemcpyAsync(scalars, a->scalars(), sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -239,7 +239,7 @@ void BindGmm(py::module_& m) {
       .def("add_pdf", &AmDiagGmm::AddPdf, py::arg("gmm"))
       .def("copy_from_am_diag_gmm", &AmDiagGmm::CopyFromAmDiagGmm, py::arg("other"))
       .def("get_pdf", [](AmDiagGmm& a, int i) { return a.GetPdf(i); }, py::arg("pdf_index"))      // reference-returning, like the reference's binding
-      .def_property("_pdfs", [](AmDiagGmm& a) { return a.pdfs(); }, [](AmDiagGmm& a, std::vector<std::shared_ptr<DiagGmm>> v) { a.pdfs() = std::move(v); })
+      .def_property("_pdfs", [](const AmDiagGmm& a) { return a.pdfs(); }, [](AmDiagGmm& a, std::vector<std::shared_ptr<DiagGmm>> v) { a.pdfs() = std::move(v); })
       .def("compute_gconsts", &AmDiagGmm::ComputeGconsts)
       .def("log_likelihood", [](AmDiagGmm& a, int i, Arr<float> x) { return NoGil([&] { return a.GetPdf(i)->LogLikelihood(x.data(), (size_t)x.size()); }); }, py::arg("pdf_index"), py::arg("data"))
       .def("get_gaussian_mean", [](AmDiagGmm& a, int i, int g) { return Vec1(a.GetPdf(i)->GetComponentMean(g)); }, py::arg("pdf_index"), py::arg("gauss"))
@@ -267,7 +267,7 @@ void BindGmm(py::module_& m) {
       }, py::arg("gauss_off"), py::arg("weights"), py::arg("gconsts"), py::arg("means_invvars"), py::arg("inv_vars"))
       // pickle: flat tuple of 3 * num_pdfs arrays (python/csrc/am-diag-gmm.cc:47-71)
       .def(py::pickle(
-          [](AmDiagGmm& a) {
+          [](const AmDiagGmm& a) {
             py::list out;
             for (auto& p : a.pdfs()) {
               out.append(Vec1(p->weights()));
@@ -408,8 +408,30 @@ void BindGmm(py::module_& m) {
       .def_property_readonly("tot_stats_count", &AccumAmDiagGmm::TotStatsCount)
       .def_property_readonly("tot_count", &AccumAmDiagGmm::TotCount)
       .def_property_readonly("tot_log_like", &AccumAmDiagGmm::TotLogLike)
-      .def_readwrite("_total_frames", &AccumAmDiagGmm::total_frames_)
-      .def_readwrite("_total_log_like", &AccumAmDiagGmm::total_log_like_)
+      .def_property("_total_frames", &AccumAmDiagGmm::total_frames, &AccumAmDiagGmm::set_total_frames)
+      .def_property("_total_log_like", &AccumAmDiagGmm::total_log_like, &AccumAmDiagGmm::set_total_log_like)
+      // gmm_acc_stats_ali's device path (scripts/gmm_acc_stats_ali.py:46-58): K3 over (feats, ali) of one utterance into statistics that
+      // stay on the device between calls; transition_accs[tid] += 1 per frame on the host, as TransitionModel.accumulate does
+      // -> (log_like of these frames, transition_accs)
+      .def("_acc_stats_ali", [](AccumAmDiagGmm& a, const AmDiagGmm& am, const TransitionModel& tm, Arr<float> feats, std::vector<int32_t> ali, py::object tacc) {
+        if (feats.ndim() != 2 || (py::ssize_t)ali.size() != feats.shape(0)) throw Error("gmm_acc_stats_ali: feats must be 2-D and len(ali) == num_frames");
+        if (feats.shape(0) > 0 && feats.shape(1) != am.Dim()) throw Error("Dim mismatch: data dim = " + std::to_string(feats.shape(1)) + " vs. model dim = " + std::to_string(am.Dim()));
+        const int64_t fo[2] = {0, (int64_t)feats.shape(0)};
+        const double ll = NoGil([&] { return a.AccumulateAli(am, tm, feats.data(), fo, 1, ali.data()); });
+        const py::ssize_t nt = tm.NumTransitionIds() + 1;
+        py::array_t<double> t;
+        if (tacc.is_none()) { t = py::array_t<double>(nt); std::fill(t.mutable_data(), t.mutable_data() + nt, 0.0); }
+        else {
+          t = py::array_t<double>::ensure(tacc);
+          if (!t || t.ndim() != 1 || t.shape(0) != nt) throw Error("transition_accs: one count per transition-id (+ entry 0)");
+          if (!t.writeable() || !(t.flags() & py::array::c_style)) t = py::array_t<double, py::array::c_style>(t.attr("copy")());
+        }
+        double* tp = t.mutable_data();
+        for (int32_t x : ali) tp[x] += 1.0;
+        return py::make_tuple(ll, t);
+      }, py::arg("am_gmm"), py::arg("transition_model"), py::arg("feats"), py::arg("ali"), py::arg("transition_accs") = py::none())
+      .def("_flush_device_stats", [](AccumAmDiagGmm& a) { NoGil([&] { a.Flush(); return 0; }); })
+      .def_property_readonly("_has_device_stats", &AccumAmDiagGmm::HasDeviceStats)
       .def("get_acc", [](AccumAmDiagGmm& a, int i) { return std::make_shared<AccumDiagGmm>(*a.Acc(i)); }, py::arg("index"))   // the binding returns a COPY
       .def_property_readonly("_accs", [](AccumAmDiagGmm& a) { return a.accs(); })
       .def("accumulate_for_gmm", [](AccumAmDiagGmm& a, const AmDiagGmm& model, Arr<float> x, int i, float w) {

@@ -26,20 +26,39 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
   u->ctx = ctx; u->n_utt = n_utt; u->D = D;
   u->frame_off.assign(frame_off, frame_off + n_utt + 1);
   u->N = frame_off[n_utt];
+  // the reference's per-utterance call pattern (one utterance per set, a new set per call): scratch from the context's arena, one
+  // staged copy instead of a hipMalloc + pageable copy per table
+  u->small = n_utt <= 16 && u->N <= 16384 && u->N * (int64_t)D <= (int64_t)(512 << 10) && (!state_off || (state_off[n_utt] <= 32768 && arc_off && arc_off[state_off[n_utt]] <= 65536));
   int rc = KHG_OK;
   auto fail = [&](int code, const std::string& msg) { khg_utts_destroy(u); return khg_set_error(code, msg); };
   if (feats_dv) { u->feats_d = feats_dv; u->own_feats = false; }
   else {
     float* p = nullptr;
-    rc = dev_alloc(&p, (size_t)u->N * D);
+    rc = u_alloc(u, &p, (size_t)u->N * D);
     if (rc) { khg_utts_destroy(u); return rc; }
     u->feats_d = p; u->own_feats = true;
     if (u->N) {
-      hipError_t e = hipMemcpyAsync(p, feats_h, sizeof(float) * (size_t)u->N * D, hipMemcpyHostToDevice, ctx->stream);
-      if (e != hipSuccess) return fail(KHG_E_HIP, hipGetErrorString(e));
+      const size_t nb = sizeof(float) * (size_t)u->N * D;
+      if (ctx->arena.owns(p)) { memcpy(ctx->arena.mirror(p), feats_h, nb); arena_mark_dirty(ctx, p, nb); }
+      else {
+        hipError_t e = hipMemcpyAsync(p, feats_h, nb, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(KHG_E_HIP, hipGetErrorString(e));
+        ctx->pageable_pending = true;
+      }
+    }
+    if (u->small && u->N > 0) {      // the column maxima the split K1 forms scale by: a pass over 48 kB here instead of a kernel + a download
+      u->xmax.assign((size_t)D, 0.0f);
+      for (int64_t t = 0; t < u->N; ++t) {
+        const float* x = feats_h + (size_t)t * D;
+        for (int d = 0; d < D; ++d) {        // k1h_absmax's rule: -inf skipped, NaN / +inf come out as +inf
+          const float v = x[d], m = u->xmax[(size_t)d];
+          if (v == -std::numeric_limits<float>::infinity()) continue;
+          u->xmax[(size_t)d] = (std::fabs(v) <= 3.0e38f) ? std::fmax(m, std::fabs(v)) : std::numeric_limits<float>::infinity();
+        }
+      }
     }
   }
-  rc = dev_upload(ctx, &u->frame_off_d, u->frame_off);
+  rc = u_upload(ctx, u, &u->frame_off_d, u->frame_off);
   if (rc) { khg_utts_destroy(u); return rc; }
   u->pdf_off.assign(n_utt + 1, 0);
 
@@ -178,25 +197,26 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
     in_off[NS] = NA;
     std::vector<int32_t> startv(start, start + n_utt);
     std::vector<float> finalv(final_w, final_w + NS);
-    rc = dev_upload(ctx, &u->state_off_d, u->state_off);
-    if (!rc) rc = dev_upload(ctx, &u->start_d, startv);
-    if (!rc) rc = dev_upload(ctx, &u->in_off_d, in_off);
-    if (!rc) rc = dev_upload(ctx, &u->out_off_d, out_off);
-    if (!rc) rc = dev_upload(ctx, &u->in_src_d, in_src);
-    if (!rc) rc = dev_upload(ctx, &u->in_col_d, in_col);
-    if (!rc) rc = dev_upload(ctx, &u->in_tid_d, in_tid);
-    if (!rc) rc = dev_upload(ctx, &u->in_olabel_d, in_ol);
-    if (!rc) rc = dev_upload(ctx, &u->out_inidx_d, out_inidx);
-    if (!rc) rc = dev_upload(ctx, &u->in_w_d, in_w);
-    if (!rc) rc = dev_upload(ctx, &u->final_d, finalv);
-    if (!rc) rc = dev_upload(ctx, &u->bp_off_d, u->bp_off);
-    if (!rc) rc = dev_upload(ctx, &u->path_off_d, u->path_off);
-    if (!rc) rc = dev_upload(ctx, &u->words_off_d, u->words_off);
-    if (!rc) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e)); }
+    rc = u_upload(ctx, u, &u->state_off_d, u->state_off);
+    if (!rc) rc = u_upload(ctx, u, &u->start_d, startv);
+    if (!rc) rc = u_upload(ctx, u, &u->in_off_d, in_off);
+    if (!rc) rc = u_upload(ctx, u, &u->out_off_d, out_off);
+    if (!rc) rc = u_upload(ctx, u, &u->in_src_d, in_src);
+    if (!rc) rc = u_upload(ctx, u, &u->in_col_d, in_col);
+    if (!rc) rc = u_upload(ctx, u, &u->in_tid_d, in_tid);
+    if (!rc) rc = u_upload(ctx, u, &u->in_olabel_d, in_ol);
+    if (!rc) rc = u_upload(ctx, u, &u->out_inidx_d, out_inidx);
+    if (!rc) rc = u_upload(ctx, u, &u->in_w_d, in_w);
+    if (!rc) rc = u_upload(ctx, u, &u->final_d, finalv);
+    if (!rc) rc = u_upload(ctx, u, &u->bp_off_d, u->bp_off);
+    if (!rc) rc = u_upload(ctx, u, &u->path_off_d, u->path_off);
+    if (!rc) rc = u_upload(ctx, u, &u->words_off_d, u->words_off);
     if (rc) { khg_utts_destroy(u); return rc; }
   }
   plan_ll(u);
-  { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return fail(KHG_E_HIP, hipGetErrorString(e)); }
+  rc = arena_flush(ctx);
+  if (!rc) rc = sync_pageable(ctx);        // the caller's arrays and the vectors above are free after this
+  if (rc) { khg_utts_destroy(u); return rc; }
   *out = u;
   return KHG_OK;
 }
@@ -233,6 +253,18 @@ extern "C" int khg_utts_features_changed(khg_utts* u) {
 
 extern "C" int khg_utts_destroy(khg_utts* u) {
   if (!u) return KHG_OK;
+  if (u->small && u->ctx) {
+    // arena scratch is reused by the next set at once (hipFree would have waited for the device): nothing of this set may be in flight
+    khg_ctx* c = u->ctx;
+    for (int i = 0; i < khg_ctx::NSIDE; ++i)
+      if (c->side_dirty[i]) { (void)hipStreamSynchronize(c->sides[i]); c->side_dirty[i] = false; }
+    (void)hipStreamSynchronize(c->stream);
+    c->pageable_pending = false;
+  }
+  if (u->out_blk_d) {                      // ali / words / like / status live inside one block (small sets)
+    u->ali_d = nullptr; u->words_d = nullptr; u->num_words_d = nullptr; u->status_d = nullptr; u->like_d = nullptr;
+    DEVFREE(u->out_blk_d);
+  }
   if (u->own_feats) DEVFREE(u->feats_d);
   DEVFREE(u->frame_off_d); DEVFREE(u->state_off_d); DEVFREE(u->pdf_off_d); DEVFREE(u->ll_off_d);
   DEVFREE(u->pdfs_d); DEVFREE(u->wchunks_d); DEVFREE(u->start_d); DEVFREE(u->in_off_d); DEVFREE(u->out_off_d);

@@ -97,39 +97,25 @@ def gmm_align_compiled_batch(am_gmm: AmDiagGmm, transition_model: TransitionMode
 
 def gmm_acc_stats_ali(am_gmm: AmDiagGmm, gmm_accs: AccumAmDiagGmm, transition_model: TransitionModel, feats,
                       ali: List[int], transition_accs: Optional[np.ndarray] = None):
-    """scripts/gmm_acc_stats_ali.py:9-58 -> (log_like, transition_accs); gmm_accs is updated in place."""
-    return gmm_acc_stats_ali_batch(am_gmm, gmm_accs, transition_model, [feats], [ali], transition_accs)
+    """scripts/gmm_acc_stats_ali.py:9-58 -> (log_like, transition_accs); gmm_accs is updated in place.
+    One K3 pass over the utterance; the model is on the device already (cached on am_gmm, uploaded again only after it changed) and
+    the statistics STAY on the device between calls (gmm_accs adds them into its host accumulators when something reads those:
+    get_acc, tot_count, mle_am_diag_gmm_update, pickling) -- the reference's caller makes this call once per utterance."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    return gmm_accs._acc_stats_ali(am_gmm, transition_model, feats, ali, transition_accs)
 
 
 def gmm_acc_stats_ali_batch(am_gmm: AmDiagGmm, gmm_accs: AccumAmDiagGmm, transition_model: TransitionModel,
                             feats: Sequence[np.ndarray], alis: Sequence[Sequence[int]],
                             transition_accs: Optional[np.ndarray] = None):
-    feats = [np.asarray(f, np.float32) for f in feats]
-    for f, a in zip(feats, alis):
-        if f.ndim != 2 or len(a) != f.shape[0]:
-            raise KhgError("gmm_acc_stats_ali: feats must be 2-D and len(ali) == num_frames")
+    """Several utterances, same contract: -> (total log_like, transition_accs)."""
+    tot = 0.0
     if transition_accs is None:
         transition_accs = transition_model.init_stats()
-    ctx = _gpu.default_context()
-    go, gc, _, miv, iv = am_gmm.flat()
-    dm = DeviceModel(ctx, go, gc, miv, iv)
-    dt = DeviceTransitions(ctx, np.asarray(transition_model.transition_id_to_pdf_array(), np.int32))
-    frame_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
-    allf = np.concatenate(feats) if feats else np.zeros((0, am_gmm.dim), np.float32)
-    ali = np.concatenate([np.asarray(a, np.int32) for a in alis]) if alis else np.zeros(0, np.int32)
-    nt = transition_model.num_transition_ids
-    if ali.size and (ali.min() < 1 or ali.max() > nt):
-        raise KhgError("gmm_acc_stats_ali: transition-id out of range")
-    us = UtteranceSet(ctx, None, frame_off, allf)
-    us.upload_ali(ali)
-    accs = DeviceAccs(ctx, dm, dt)
-    us.acc_stats(dm, dt, accs, 1.0)
-    st = accs.download()
-    gmm_accs.add_device_stats(st, go)
-    transition_accs = np.asarray(transition_accs, np.float64)
-    transition_accs += st["trans_acc"]
-    accs.close(); us.close(); dt.close(); dm.close()
-    return st["total_log_like"], transition_accs
+    for f, a in zip(feats, alis):
+        ll, transition_accs = gmm_acc_stats_ali(am_gmm, gmm_accs, transition_model, f, a, transition_accs)
+        tot += ll
+    return tot, transition_accs
 
 
 def gmm_est(am_gmm: AmDiagGmm, gmm_accs: AccumAmDiagGmm, transition_model: TransitionModel, transition_accs,

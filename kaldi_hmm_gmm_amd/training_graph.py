@@ -225,8 +225,11 @@ class TrainingGraphCompiler:
             if k == n and L.is_final(ls):
                 finals[src] = float(L.final(ls))
             for a in L.arcs(ls):
+                # disambig_syms are PHONE-table ids: they name input labels only (csrc/training-graph-compiler.cc:20-140 removes
+                # them from the phone side after composing L with the transcript on the real word ids) -- an output label is a word
+                # id from another table and is epsilon only when it is 0, whatever number a disambiguation phone happens to carry
                 ph = 0 if (a.ilabel == 0 or a.ilabel in dis) else a.ilabel
-                if a.olabel == 0 or a.olabel in dis:
+                if a.olabel == 0:
                     raw.append((src, get(a.nextstate, k), ph, 0, float(a.weight)))
                 elif k < n and a.olabel == transcript[k]:
                     raw.append((src, get(a.nextstate, k + 1), ph, a.olabel, float(a.weight)))

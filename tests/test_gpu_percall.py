@@ -1,0 +1,178 @@
+"""The reference's own call pattern (egs/yesno/train.py:170-202): gmm_align_compiled + gmm_acc_stats_ali once per utterance, with
+the reference's keyword arguments, against the batched device path on the same utterances -- at a model far above the recipe's
+(2000 pdfs x 32 Gaussians x 40 dims: one upload of it per call would dominate everything).
+
+What is checked: identical alignments; statistics within the tolerance of tests/test_gpu_parity.py; the per-call log-likelihoods;
+the transition counts; that the device state cached on the host objects follows their mutations (a changed pdf is seen by the
+next call, a copy made by gmm_boost_silence is its own model) and that every host-side reader of AccumAmDiagGmm sees the
+statistics that were still on the device."""
+import pickle
+
+import numpy as np
+import pytest
+
+from kaldi_hmm_gmm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def khg(ctx):
+    import kaldi_hmm_gmm_amd as k
+    from kaldi_hmm_gmm_amd import _gpu
+    _gpu.set_default_context(ctx)
+    return k
+
+
+def _batched(khg, ctx, m, am, ut, n, cost, beam, retry_beam):
+    go, gc, _, miv, iv = am.flat()
+    dm = khg.DeviceModel(ctx, go, gc, miv, iv)
+    tm = khg.DeviceTransitions(ctx, m.id2pdf)
+    tm.set_trans_cost(cost)
+    fo = ut.frame_off[: n + 1]
+    g = ut.graphs
+    so = g["state_off"][: n + 1]
+    ao = g["arc_off"][: so[-1] + 1]
+    sub = {"state_off": so, "start": g["start"][:n], "arc_off": ao, "ilabel": g["ilabel"][: ao[-1]], "olabel": g["olabel"][: ao[-1]],
+           "weight": g["weight"][: ao[-1]], "nextstate": g["nextstate"][: ao[-1]], "final": g["final"][: so[-1]]}
+    us = khg.UtteranceSet(ctx, tm, fo, ut.feats[: fo[-1]], graphs=sub)
+    us.loglikes(dm, reachable_only=True)
+    res = us.align(tm, beam=beam, retry_beam=retry_beam, acoustic_scale=0.1)
+    accs = khg.DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs)
+    st = accs.download()
+    accs.close(); us.close(); tm.close(); dm.close()
+    return res, st
+
+
+@pytest.mark.parametrize("beam,retry_beam", [(200.0, 0.0), (6.0, 40.0)])
+def test_per_utterance_calls_equal_the_batched_path(khg, ctx, beam, retry_beam):
+    P, G, D, n = 2000, 32, 40, 24
+    m = synth.make_model(P, G, D, seed=77)
+    ut = synth.make_utts(m, n, seed=9, min_phones=4, max_phones=30)
+    am, tm = synth.host_objects(m)
+    assert tm.num_transition_ids == 2 * 3 * (P // 3)
+    np.testing.assert_array_equal(np.asarray(tm.transition_id_to_pdf_array())[1:], m.id2pdf[1: tm.num_transition_ids + 1])
+    cfg = khg.AlignConfig(beam=beam, retry_beam=retry_beam, careful=False)
+    gmm_accs = khg.AccumAmDiagGmm()
+    gmm_accs.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    transition_accs = None
+    alis, lls, likes, frames = [], [], [], 0
+    for u in range(n):
+        feats = np.ascontiguousarray(ut.feats[ut.frame_off[u]: ut.frame_off[u + 1]])
+        ans = khg.gmm_align_compiled(am_gmm=am, transition_model=tm, utt=f"utt{u}", fst=synth.utt_fst(ut.graphs, u), feats=feats, align_config=cfg,
+                                     acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+        assert ans["num_done"] == 1 and ans["frame_count"] == feats.shape[0]
+        alis.append(np.asarray(ans["alignment"], np.int32)); likes.append(ans["tot_like"])
+        log_like, transition_accs = khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=gmm_accs, transition_model=tm, feats=feats, ali=ans["alignment"],
+                                                          transition_accs=transition_accs)
+        lls.append(log_like); frames += feats.shape[0]
+    assert gmm_accs._has_device_stats            # nothing has crossed PCIe but the scalars
+    cost = np.asarray(tm.scaled_trans_cost(1.0, 0.1), np.float32)
+    cost_full = np.zeros(m.num_tids + 1, np.float32); cost_full[: cost.shape[0]] = cost
+    res, st = _batched(khg, ctx, m, am, ut, n, cost_full, beam, retry_beam)
+    np.testing.assert_array_equal(np.concatenate(alis), res["ali"])
+    np.testing.assert_allclose(likes, res["like"], rtol=1e-6)
+    # host-side readers see the device statistics
+    assert gmm_accs.tot_count == pytest.approx(frames)
+    assert not gmm_accs._has_device_stats
+    occ = np.concatenate([np.asarray(gmm_accs.get_acc(p).occupancy) for p in range(P)])
+    mean = np.concatenate([np.asarray(gmm_accs.get_acc(p).mean_accumulator) for p in range(P)])
+    var = np.concatenate([np.asarray(gmm_accs.get_acc(p).variance_accumulator) for p in range(P)])
+    np.testing.assert_allclose(occ, st["occ"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(mean, st["mean_acc"], rtol=2e-5, atol=2e-6 * np.abs(st["mean_acc"]).max())
+    np.testing.assert_allclose(var, st["var_acc"], rtol=2e-5, atol=2e-6 * np.abs(st["var_acc"]).max())
+    assert sum(lls) == pytest.approx(st["total_log_like"], rel=1e-9)
+    assert gmm_accs.tot_log_like == pytest.approx(st["total_log_like"], rel=1e-6)
+    want_t = np.bincount(np.concatenate(alis), minlength=tm.num_transition_ids + 1).astype(np.float64)
+    np.testing.assert_array_equal(transition_accs, want_t)
+    # the update reads the flushed accumulators
+    r = khg.mle_am_diag_gmm_update(config=khg.MleDiagGmmOptions(), amdiag_gmm_acc=gmm_accs, flags=khg.GmmUpdateFlags.kGmmAll, am_gmm=am)
+    assert r[1] == pytest.approx(frames, rel=1e-5)
+
+
+def test_cached_device_model_follows_the_host_object(khg, ctx):
+    P, G, D = 60, 8, 13
+    m = synth.make_model(P, G, D, seed=5)
+    ut = synth.make_utts(m, 3, seed=2, min_phones=3, max_phones=6)
+    am, tm = synth.host_objects(m)
+    feats = np.ascontiguousarray(ut.feats[ut.frame_off[0]: ut.frame_off[1]])
+    ali = [int(x) for x in ut.ref_ali[ut.frame_off[0]: ut.frame_off[1]]]
+
+    def run(model):
+        a = khg.AccumAmDiagGmm(); a.init(model=model, flags=khg.GmmUpdateFlags.kGmmAll)
+        ll, _ = khg.gmm_acc_stats_ali(am_gmm=model, gmm_accs=a, transition_model=tm, feats=feats, ali=ali)
+        return ll, a
+
+    ll0, _ = run(am)
+    ll0b, _ = run(am)
+    assert ll0 == ll0b
+    # a mutation through the reference-returning get_pdf(i) must reach the device
+    p0 = int(ut.frame_pdf[ut.frame_off[0]])
+    g = am.get_pdf(p0)
+    g.set_means(np.asarray(g.means) + np.float32(0.5))
+    g.compute_gconsts()
+    ll1, _ = run(am)
+    assert ll1 != ll0
+    fresh = khg.AmDiagGmm(); fresh.copy_from_am_diag_gmm(am)
+    ll1f, _ = run(fresh)
+    assert ll1f == ll1
+    # gmm_boost_silence returns a COPY with other weights: its own device model, the original's stays what it was
+    boosted = khg.gmm_boost_silence(am_gmm=am, transition_model=tm, silence_phones=[p0 // 3 + 1], boost=3.0)
+    ll2, _ = run(boosted)
+    assert ll2 != ll1
+    ll1c, _ = run(am)
+    assert ll1c == ll1
+    # pickling the accumulators reads the device statistics; an AccumAmDiagGmm copy is a deep copy of them
+    _, a = run(am)
+    assert a._has_device_stats
+    b = khg.AccumAmDiagGmm(); b.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    b.add(1.0, a)
+    assert b.tot_count == pytest.approx(len(ali)) and a.tot_count == pytest.approx(len(ali))
+    am2 = pickle.loads(pickle.dumps(am))
+    ll3, _ = run(am2)
+    assert ll3 == pytest.approx(ll1, rel=1e-6)
+
+
+def test_align_after_the_band_model_changed_or_died_is_an_error(khg, ctx):
+    """khg_loglikes_band keeps pointers into the model for khg_align's repair launch: a model destroyed or updated in between must
+    give an error, not a use-after-free; a model whose fp16 image was merely re-packed (another set lowered the shared feature
+    exponents) makes khg_align score the set again, with identical alignments."""
+    P, G, D = 90, 24, 40
+    m = synth.make_model(P, G, D, seed=3)
+    ut = synth.make_utts(m, 12, seed=4, min_phones=3, max_phones=8)
+    import kaldi_hmm_gmm_amd as k
+    gc = np.zeros(m.weights.shape[0], np.float32)
+    from kaldi_hmm_gmm_amd import _lib
+    import ctypes as C
+    _lib.check(_lib.lib.khg_compute_gconsts(P, D, _lib.ptr(m.gauss_off, C.c_int32), _lib.ptr(m.weights, C.c_float), _lib.ptr(m.inv_vars, C.c_float),
+                                            _lib.ptr(m.means_invvars, C.c_float), _lib.ptr(gc, C.c_float), None))
+    tm = k.DeviceTransitions(ctx, m.id2pdf)
+
+    def new_set(scale=1.0):
+        return k.UtteranceSet(ctx, tm, ut.frame_off, (ut.feats * np.float32(scale)).astype(np.float32), graphs=ut.graphs)
+
+    dm = k.DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    us = new_set()
+    us.loglikes(dm, reachable_only=True, band=True)
+    want = us.align(tm, beam=200.0, acoustic_scale=0.1)
+    # (1) the image re-packed for another set's (much larger) features: align must still give the same answer, at a beam that sends
+    # every utterance through the repair
+    us.loglikes(dm, reachable_only=True, band=True)
+    big = new_set(scale=37.0)
+    big.loglikes(dm, reachable_only=True, band=True)
+    got = us.align(tm, beam=1e-3, retry_beam=200.0, acoustic_scale=0.1)
+    np.testing.assert_array_equal(got["ali"], want["ali"])
+    big.close()
+    # (2) updated in place
+    us.loglikes(dm, reachable_only=True, band=True)
+    dm.set_weights(m.weights)
+    dm.scale_weights(np.asarray([0, 1], np.int32), 1.5)
+    with pytest.raises(k.KhgError, match="destroyed or updated"):
+        us.align(tm, beam=200.0, acoustic_scale=0.1)
+    # (3) destroyed
+    us.loglikes(dm, reachable_only=True, band=True)
+    dm.close()
+    with pytest.raises(k.KhgError, match="destroyed or updated"):
+        us.align(tm, beam=200.0, acoustic_scale=0.1)
+    us.close(); tm.close()

@@ -219,3 +219,28 @@ def test_lexicon_fst_form_equals_dict_form(sil_disambig):
         assert word_ids == list(words)
     with pytest.raises(Exception):
         gc.compile_graph_from_text([5])                      # a word the lexicon FST does not have
+
+
+def test_word_id_equal_to_a_disambiguation_phone_id_is_still_a_word():
+    """disambig_syms are phone-table ids (csrc/training-graph-compiler.cc:20-140 applies them to the INPUT side only); word ids come
+    from another table and may carry the same numbers.  Word 7 below collides with the disambiguation phone #0 = 7: its arc must
+    stay a word arc -- the transcript [1, 7] compiles, and the graph of [1, 2] must not accept a path through word 7."""
+    from kaldi_hmm_gmm_amd import TrainingGraphCompiler, TrainingGraphCompilerOptions, equal_align, make_lexicon_fst_with_silence
+
+    topo, cd, tm, _ = _setup(True)
+    lex = {1: [(1.0, [2])], 2: [(1.0, [3])], 7: [(1.0, [4])]}
+    L = make_lexicon_fst_with_silence(lex, sil_phone=1, sil_prob=0.5)
+    gc = TrainingGraphCompiler(trans_model=tm, ctx_dep=cd, lex_fst=L, disambig_syms=[7, 8, 9], opts=TrainingGraphCompilerOptions())
+    g17 = gc.compile_graph_from_text([1, 7])
+    ok, ali17 = equal_align(ifst=g17, length=50, rand_seed=1, num_retries=10)
+    assert ok and _walk(g17, ali17) is not None
+    phones17 = {tm.transition_id_to_phone(t) for t in ali17}
+    assert {2, 4} <= phones17 and 3 not in phones17
+    g12 = gc.compile_graph_from_text([1, 2])
+    assert _walk(g12, ali17) is None                         # word 7's phones are not a free detour of the graph for [1, 2]
+    ok, ali12 = equal_align(ifst=g12, length=50, rand_seed=1, num_retries=10)
+    assert ok and 4 not in {tm.transition_id_to_phone(t) for t in ali12}
+    # every phone on any arc of the graph for [1, 2] belongs to words 1, 2 or to silence
+    for s in range(g12.num_states):
+        for a in g12.arcs(s):
+            assert tm.transition_id_to_phone(a.ilabel) in (1, 2, 3)
