@@ -55,6 +55,12 @@ def parse():
                          "torch.distributed.all_reduce on a view of the block; khg-f32 = the fp32-wire tolerance experiment; "
                          "host = block summed over gloo on the host (test rig: KHG_BENCH_SHARE_GPU=1 puts every rank on GPU 0, "
                          "where RCCL refuses to form a communicator)")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="form the process group and the library's RCCL communicator, all-reduce 1 MB through both, print one JSON line and "
+                         "exit -- seconds, before any data is built: what the self-launcher runs first so that a broken RCCL costs no synthesis")
+    ap.add_argument("--per-call-utts", type=int, default=int(os.environ.get("KHG_BENCH_PERCALL_UTTS", "256")),
+                    help="utterances pushed through gmm_align_compiled + gmm_acc_stats_ali ONE CALL EACH after the timed region (per_call_line); 0 = skip")
+    ap.add_argument("--no-recipe-beam-line", action="store_true", help="skip the two extra steps at the recipe's beam 6 / retry 40 (recipe_beam_line)")
     ap.add_argument("--c1-parts", type=int, default=4,
                     help="--allreduce khg: C1 pipelined behind K3 in this many pdf ranges (khg_acc_stats_reduce); 1 = one all-reduce of the "
                          "whole block behind K3 (khg_accs_allreduce)")
@@ -62,33 +68,70 @@ def parse():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` from a bare shell: N fresh child processes, one per GPU, under
-    torch.distributed.run.  This process has imported neither torch nor the library: nothing here has initialised
-    a GPU, and nothing is exec'ed -- the children are ordinary subprocesses whose return code becomes ours."""
+    """`python bench.py --gpus N` from a bare shell: N fresh child processes, one per GPU, under torch.distributed.run.  This process
+    has imported neither torch nor the library: nothing here has initialised a GPU, and nothing is exec'ed -- the children are
+    ordinary subprocesses.  The first N > 1 run must not be wasted on one broken piece of the exchange, so the launch walks a LADDER,
+    every rung in FRESH children (never a retry inside a process that has touched a GPU):
+      0. --dist-selftest with the requested exchange: process group + communicator + a 1 MB all-reduce, seconds, no data built;
+      1. the bench as asked (--allreduce khg, C1 pipelined behind K3 by the library's own RCCL calls);
+      2. --allreduce torch (torch.distributed's all-reduce on a view of the block);
+      3. --allreduce khg --c1-parts 1 (one un-pipelined all-reduce by the library).
+    What failed on the way is recorded in the line that finally prints ("allreduce_fallback")."""
     import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-    err = r.stderr.decode("utf-8", "replace")
-    lines = [ln for ln in r.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
-    if lines:
-        print(lines[-1], flush=True)
-    if r.returncode or not lines:
-        # what the ranks said last: torch.distributed.run names the failing rank, the ranks' own messages sit above that
-        tail = err.splitlines()[-60:]
-        print(f"bench.py: the {args.gpus}-rank launch ended with return code {r.returncode}; last lines of its stderr:", file=sys.stderr)
-        for ln in tail:
+    def run(extra, timeout):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        base = [a for a in sys.argv[1:]]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + base + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
+            rc, out, err = r.returncode, r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
+        except subprocess.TimeoutExpired as ex:
+            rc, out, err = 124, (ex.stdout or b"").decode("utf-8", "replace"), (ex.stderr or b"").decode("utf-8", "replace") + f"\n[self_launch] timed out after {timeout} s"
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        return rc, (lines[-1] if lines else None), err
+
+    asked = args.allreduce
+    rungs = [("as asked (--allreduce %s, --c1-parts %d)" % (asked, args.c1_parts), [])]
+    if asked == "khg":
+        rungs += [("--allreduce torch", ["--allreduce", "torch"]), ("--allreduce khg --c1-parts 1", ["--allreduce", "khg", "--c1-parts", "1"])]
+    tried = []
+    t_self = float(os.environ.get("KHG_BENCH_SELFTEST_TIMEOUT", "300"))
+    t_run = float(os.environ.get("KHG_BENCH_RUN_TIMEOUT", "3000"))
+    for k, (name, extra) in enumerate(rungs):
+        if not args.dist_selftest:
+            rc, line, err = run(extra + ["--dist-selftest"], t_self)
+            if rc or not line:
+                tried.append({"tried": name + " [selftest]", "rc": rc, "stderr_tail": [ln for ln in err.splitlines() if ln.startswith("bench.py:")][-4:] + err.splitlines()[-8:]})
+                print(f"bench.py: dist selftest failed on rung {k} ({name}), rc {rc}; trying the next rung", file=sys.stderr)
+                continue
+        rc, line, err = run(extra, t_run)
+        if rc == 0 and line:
+            if tried:
+                try:
+                    d = json.loads(line)
+                    d["allreduce_fallback"] = tried
+                    line = json.dumps(d)
+                except Exception:
+                    pass
+            print(line, flush=True)
+            sys.stderr.write(err[-2000:])
+            sys.exit(0)
+        tried.append({"tried": name, "rc": rc, "stderr_tail": [ln for ln in err.splitlines() if ln.startswith("bench.py:")][-4:] + err.splitlines()[-8:]})
+        print(f"bench.py: the {args.gpus}-rank launch on rung {k} ({name}) ended with return code {rc}; last lines of its stderr:", file=sys.stderr)
+        for ln in err.splitlines()[-60:]:
             print("  | " + ln, file=sys.stderr)
-    else:
-        sys.stderr.write(err[-2000:])
-    sys.exit(r.returncode if r.returncode else (0 if lines else 3))
+        if args.dist_selftest:
+            break
+    print(json.dumps({"metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss", "value": None, "n_gpus": args.gpus,
+                      "error": "every rung of the launch ladder failed", "allreduce_fallback": tried}), flush=True)
+    sys.exit(3)
 
 
 def csrc_sha():
@@ -214,29 +257,6 @@ def cpu_baseline(model, gc, ut, cost, feats_host, budget_s, beam=200.0, retry_be
                       f"next {done[1]} utterances ({done[0]} frames) in {dtb:.1f}s"}
 
 
-def shard_efficiency(args, world, per_rank, kernel_ms):
-    """How close this N-rank run is to N times one GPU working on a shard of THIS size: rank 0's kernel time per step against the
-    committed N = 1 line of the same shard size (profiles/r4_shard_lines.json: bench.py --utts <utts / N>), i.e. what the exchange
-    and the imbalance between shards cost, with the small-shard effect (fewer, shorter launches per kernel) taken out."""
-    if world <= 1:
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r4_shard_lines.json")) as fh:
-            lines = json.load(fh)
-    except Exception:
-        return {"value": None, "why": "no profiles/r4_shard_lines.json"}
-    key = f"{args.config}:{args.utts // world}"
-    ref = lines.get(key)
-    if not ref:
-        return {"value": None, "why": f"no committed N = 1 line for {key}"}
-    mine = sum(v for k, v in kernel_ms.items() if not k.startswith("c1_")) / args.steps
-    slowest = max(sum(v for k, v in r["kernel_ms_per_step"].items() if not k.startswith("c1_")) for r in per_rank)
-    return {"value": ref["ms_per_step"] / max(r["seconds"] * 1e3 / args.steps for r in per_rank),
-            "n1_shard_ms_per_step": ref["ms_per_step"], "n1_shard_kernel_ms": ref["kernel_ms"], "rank0_kernel_ms": mine, "slowest_rank_kernel_ms": slowest,
-            "note": "n1_shard_ms_per_step / this run's slowest rank's ms per step; 1.0 = the shard runs as fast as it does alone on one GPU "
-                    "(exchange fully hidden, shards balanced)"}
-
-
 def check_vs_oracle(ans, ut, feats, D, sets, ctx, model, gc, tm, args):
     """Parity at the benchmark's scale, after the timed region: the product's alignment of the utterances the CPU baseline
     just aligned (K1 + K2 once more with the results downloaded) against the oracle's, utterance by utterance, and K3 over exactly
@@ -292,6 +312,97 @@ def check_vs_oracle(ans, ut, feats, D, sets, ctx, model, gc, tm, args):
                     "folded in (<= 2e-5 passes)"}
 
 
+def per_call_line(args, model, ut, feats, D, ctx, cpu_base):
+    """The reference's OWN call pattern at the benchmark's model size (egs/yesno/train.py:170-202): one gmm_align_compiled(...) and one
+    gmm_acc_stats_ali(...) per utterance, the reference's keyword arguments, host numpy features and a StdVectorFst copy per call --
+    after the timed region.  Alignments must equal the batched path's, statistics agree within 2e-5."""
+    import kaldi_hmm_gmm_amd as khg
+    from kaldi_hmm_gmm_amd import _gpu, synth
+
+    n = int(min(args.per_call_utts, len(ut.frame_off) - 1))
+    nw = min(8, n // 4)                                     # warm-up calls: the model's upload, the fp16 image settling on the exponents
+    _gpu.set_default_context(ctx)
+    t0 = time.perf_counter()
+    am, tmh = synth.host_objects(model)
+    t_host = time.perf_counter() - t0
+    fh = feats[: int(ut.frame_off[n])].cpu().numpy()
+    fl = [np.ascontiguousarray(fh[int(ut.frame_off[u]): int(ut.frame_off[u + 1])]) for u in range(n)]
+    fsts = [synth.utt_fst(ut.graphs, u) for u in range(n)]
+    cfg = khg.AlignConfig(beam=args.beam, retry_beam=args.retry_beam, careful=False)
+
+    def one(u, gmm_accs, tacc):
+        ans = khg.gmm_align_compiled(am_gmm=am, transition_model=tmh, utt=str(u), fst=fsts[u].copy(), feats=fl[u], align_config=cfg,
+                                     acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+        t1 = time.perf_counter()
+        ll, tacc = khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=gmm_accs, transition_model=tmh, feats=fl[u], ali=ans["alignment"], transition_accs=tacc)
+        return ans, ll, tacc, t1
+
+    warm = khg.AccumAmDiagGmm(); warm.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    t0 = time.perf_counter()
+    one(0, warm, None)
+    t_first = time.perf_counter() - t0
+    for u in range(1, nw):
+        one(u, warm, None)
+    del warm
+    gmm_accs = khg.AccumAmDiagGmm(); gmm_accs.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    tacc, alis, t_align, t_acc, done, tot_ll = None, [], 0.0, 0.0, 0, 0.0
+    import gc as pygc
+    pygc.collect(); pygc.disable()
+    t_begin = time.perf_counter()
+    for u in range(n):
+        ta = time.perf_counter()
+        ans, ll, tacc, t1 = one(u, gmm_accs, tacc)
+        tb = time.perf_counter()
+        t_align += t1 - ta; t_acc += tb - t1
+        alis.append(np.asarray(ans["alignment"], np.int32)); done += ans["num_done"]; tot_ll += ll
+    dt = time.perf_counter() - t_begin
+    pygc.enable()
+    frames = int(ut.frame_off[n])
+    t0 = time.perf_counter()
+    tot_count = gmm_accs.tot_count                      # the first host-side read: the device statistics come down once
+    t_flush = time.perf_counter() - t0
+    # the batched path on the same utterances, same parameters
+    go, gc_, _, miv, iv = am.flat()
+    dmb = khg.DeviceModel(ctx, go, gc_, miv, iv)
+    tmb = khg.DeviceTransitions(ctx, np.asarray(tmh.transition_id_to_pdf_array(), np.int32))
+    tmb.set_trans_cost(np.asarray(tmh.scaled_trans_cost(1.0, 0.1), np.float32))
+    g = ut.graphs
+    so = g["state_off"][: n + 1]
+    ao = g["arc_off"][: so[-1] + 1]
+    sub = {"state_off": so, "start": g["start"][:n], "arc_off": ao, "ilabel": g["ilabel"][: ao[-1]], "olabel": g["olabel"][: ao[-1]],
+           "weight": g["weight"][: ao[-1]], "nextstate": g["nextstate"][: ao[-1]], "final": g["final"][: so[-1]]}
+    us = khg.UtteranceSet(ctx, tmb, ut.frame_off[: n + 1].astype(np.int64), fh, graphs=sub)
+    us.loglikes(dmb, reachable_only=True)
+    res = us.align(tmb, beam=args.beam, retry_beam=args.retry_beam, acoustic_scale=0.1)
+    accb = khg.DeviceAccs(ctx, dmb, tmb)
+    us.acc_stats(dmb, tmb, accb)
+    st = accb.download()
+    accb.close(); us.close(); tmb.close(); dmb.close()
+    ali_equal = bool(np.array_equal(np.concatenate(alis), np.asarray(res["ali"])))
+    P = model.num_pdfs
+    occ = np.concatenate([np.asarray(a.occupancy) for a in gmm_accs._accs])
+    mean = np.concatenate([np.asarray(a.mean_accumulator).ravel() for a in gmm_accs._accs])
+    var = np.concatenate([np.asarray(a.variance_accumulator).ravel() for a in gmm_accs._accs])
+
+    def rel(a, b, atol):
+        return float(np.max(np.abs(a - b) / (np.abs(b) + atol)))
+    mm, vm = float(np.abs(st["mean_acc"]).max()), float(np.abs(st["var_acc"]).max())
+    errs = (rel(occ, st["occ"], 1e-6 / 2e-5), rel(mean, st["mean_acc"].ravel(), 2e-6 * mm / 2e-5), rel(var, st["var_acc"].ravel(), 2e-6 * vm / 2e-5))
+    one_thr = (cpu_base or {}).get("one_thread_value")
+    return {"value": frames / dt, "unit": "frames/s", "utterances": n, "frames": frames, "warmup_calls": nw,
+            "ms_per_utt": dt / n * 1e3, "ms_per_utt_align": t_align / n * 1e3, "ms_per_utt_acc_stats": t_acc / n * 1e3,
+            "first_call_ms": t_first * 1e3, "host_objects_s": t_host, "accumulator_flush_ms": t_flush * 1e3,
+            "num_done": int(done), "ali_identical_to_batched": ali_equal,
+            "max_rel_err_occ": errs[0], "max_rel_err_mean_acc": errs[1], "max_rel_err_var_acc": errs[2], "stats_within_2e-5": bool(max(errs) <= 2e-5),
+            "tot_count": float(tot_count), "sum_log_like": tot_ll, "batched_total_log_like": st["total_log_like"],
+            "vs_cpu_one_thread": (frames / dt) / one_thr if one_thr else None,
+            "note": "after the timed region: gmm_align_compiled(am_gmm=, transition_model=, utt=, fst=<copy>, feats=<host numpy>, align_config=, "
+                    "acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1) + gmm_acc_stats_ali(am_gmm=, gmm_accs=, transition_model=, "
+                    "feats=, ali=, transition_accs=) once per utterance (egs/yesno/train.py:170-202); the model and the transition table are "
+                    "cached on the device by the host objects' mutation version (first_call_ms holds the one upload), the statistics stay on "
+                    "the device until something reads them (accumulator_flush_ms); vs_cpu_one_thread = value / cpu_baseline.one_thread_value"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -311,6 +422,7 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    asked_allreduce = args.allreduce
     share_gpu = os.environ.get("KHG_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local, args.allreduce = 0, "host"
@@ -331,6 +443,56 @@ def main():
     from kaldi_hmm_gmm_amd import Context, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet, synth
     from kaldi_hmm_gmm_amd import _lib
     import ctypes as C
+
+    # test hook of the launch ladder (tests/test_bench_contract.py): the exchange as asked for on the command line "cannot form its
+    # communicator" -- every rank exits 3 the way a real failure does, and the self-launcher has to get a line out of a later rung
+    asked_khg_piped = asked_allreduce == "khg" and args.c1_parts > 1
+    if os.environ.get("KHG_BENCH_FAIL_COMM") == "1" and dist_on and asked_khg_piped:
+        print(f"bench.py: rank {rank}/{world}: KHG_BENCH_FAIL_COMM=1: pretending the library's RCCL communicator could not be formed", file=sys.stderr, flush=True)
+        os._exit(3)
+    if args.dist_selftest:
+        # seconds, before any data: process group -> (library communicator) -> a 1 MB accumulator block all-reduced the way the bench
+        # is about to do it; the sums are checked
+        from kaldi_hmm_gmm_amd.dist import make_comm
+        t_s = time.perf_counter()
+        sm = synth.make_model(25, 64, 40, seed=1)                    # 1600 Gaussians x 81 doubles = 1.04 MB of accumulators
+        sgc = np.zeros(sm.weights.shape[0], np.float32)
+        _lib.check(_lib.lib.khg_compute_gconsts(25, 40, _lib.ptr(sm.gauss_off, C.c_int32), _lib.ptr(sm.weights, C.c_float), _lib.ptr(sm.inv_vars, C.c_float),
+                                                _lib.ptr(sm.means_invvars, C.c_float), _lib.ptr(sgc, C.c_float), None))
+        sctx = Context(local)
+        sdm = DeviceModel(sctx, sm.gauss_off, sgc, sm.means_invvars, sm.inv_vars)
+        stm = DeviceTransitions(sctx, sm.id2pdf)
+        sacc = DeviceAccs(sctx, sdm, stm)
+        blk = np.full(sacc.size, float(rank + 1), np.float64)
+        sacc.upload(blk)
+        how = args.allreduce
+        if dist_on and how in ("khg", "khg-f32"):
+            scomm = make_comm(sctx, one_rank=True, timeout_s=float(os.environ.get("KHG_BENCH_COMM_TIMEOUT", "180")))
+            sacc.allreduce(scomm)
+            sctx.sync()
+            got = sacc.download()["occ"][0]
+            scomm.close()
+        elif dist_on and how == "torch":
+            tt = sacc.as_torch()
+            dist.all_reduce(tt)
+            torch.cuda.synchronize()
+            got = float(tt[0])
+        elif dist_on:
+            tt = torch.from_numpy(blk)
+            dist.all_reduce(tt)
+            got = float(tt[0])
+        else:
+            got = 1.0
+        want = world * (world + 1) / 2.0
+        ok = abs(got - want) < 1e-9
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"selftest": "ok" if ok else "WRONG SUM", "allreduce": how, "n_gpus": world, "sum": got, "want": want,
+                                           "bytes": int(sacc.size) * 8, "seconds": time.perf_counter() - t_s}) + "\n").encode())
+        os.close(json_fd)
+        sys.exit(0 if ok else 4)
 
     P, G, D = synth.CONFIGS[args.config]
     model = synth.make_model(P, G, D, seed=args.seed)
@@ -451,17 +613,21 @@ def main():
     dbg = os.environ.get("KHG_BENCH_HOSTDBG") == "1"
     dbg_marks = []
 
-    def step():
+    def step(exchange=True):
         if dbg:
             tt = [time.perf_counter()]
             gm = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             gm[0].record(streams[0])
         accs.zero()                                   # on stream 0
+        # One EM iteration changes the parameters once: what the library derives PER PARAMETER VERSION (the fp16 model image, the BAND
+        # form's upper bounds, the model's column maxima and scale exponents) is dropped here, so every timed step pays it again
+        # as a real iteration does (round 4 left 0.44 ms of it outside the timed region).
+        dm.invalidate()
         if dbg: gm[1].record(streams[0])
         ev_a.record(streams[0])
         for st in streams[1:]:
             st.wait_event(ev_a)
-        piped = dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1
+        piped = exchange and dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1
         for s_ in sets:                               # batches alternate between the two streams
             if dbg: tt.append(time.perf_counter())
             s_.loglikes(dm, reachable_only=not args.full_loglikes, band=band)
@@ -475,7 +641,7 @@ def main():
             print("step host ms:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in zip(tt[:-1], tt[1:])), file=sys.stderr)
         for st in streams[1:]:
             ev_b.record(st); streams[0].wait_event(ev_b)
-        if dist_on:                                   # C1, on stream 0 right behind K3: no host synchronisation
+        if dist_on and exchange:                      # C1, on stream 0 right behind K3: no host synchronisation
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(streams[0])
             if piped:                                 # the last set's K3 with the exchange pipelined behind it by pdf ranges
@@ -502,7 +668,7 @@ def main():
         if w == 0:
             for c in ctxs:
                 for name, ms in c.timings():
-                    if name in ("k1_absmax", "k1s_pack_x", "k0s_pack_tiles", "k1h_pack_x", "k0h_pack_tiles", "k0b_pack_tiles"):
+                    if name in ("k1_absmax", "k1s_pack_x", "k1h_pack_x"):
                         prep_ms[name] = prep_ms.get(name, 0.0) + ms
                 c.set_timing(False)
     torch.cuda.synchronize()
@@ -553,6 +719,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         frames_total = int(t[1])
+    # The same shards WITHOUT the exchange, in this very run (round 4 compared with a committed N = 1 line of another box and session):
+    # two steps, every rank alone on its shard, slowest rank's time -- what an N-rank run would cost if C1 were free
+    alone_ms = None
+    if dist_on and world > 1:
+        step(exchange=False)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(2):
+            step(exchange=False)
+        torch.cuda.synchronize()
+        tl = torch.tensor([time.perf_counter() - ta], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        alone_ms = float(tl[0]) / 2 * 1e3
+        step()                                        # the block holds the sum over all shards again (what `check` and the M-step read)
+        torch.cuda.synchronize()
+        del ar_events[args.steps:]
+        for c in ctxs:
+            c.timings()                               # (drained: these steps are not part of kernel_ms)
     # C1 once more, un-pipelined and alone on the stream (nothing to hide behind): what the exchange itself costs at this N
     rccl_info = None
     if dist_on and args.allreduce in ("khg", "khg-f32"):
@@ -618,6 +802,57 @@ def main():
                      "roofline_frac": k1_flops_per_launch / (k1_32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if k1_32 else None}
         ar_events[:] = ar_events[: args.steps]
 
+    # the recipe's own beams (egs/yesno/train.py:165-167: beam 6, retry 40) on the same set: no band (a narrow beam fails many
+    # certificates: khg_loglikes_reachable), two timed steps, then who was retried / went through the order-faithful decoder
+    recipe_line = None
+    if not args.no_recipe_beam_line and args.beam != 6.0:
+        def step_recipe(download=False):
+            accs.zero()
+            dm.invalidate()
+            st_all = []
+            for s_ in sets:
+                s_.loglikes(dm, reachable_only=True, band=False)
+                r_ = s_.align(tm, beam=6.0, retry_beam=40.0, acoustic_scale=0.1, download="summary" if download else False)
+                if download:
+                    st_all.append(np.asarray(r_["status"]))
+            for s_ in sets:
+                s_.acc_stats(dm, tm, accs)
+            return st_all
+        step_recipe()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.sync(); c.set_timing(True)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step_recipe()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        dtr = time.perf_counter() - t0
+        kr = {}
+        for c in ctxs:
+            for name, ms in c.timings():
+                kr[name] = kr.get(name, 0.0) + ms
+            c.set_timing(False)
+        st = np.concatenate(step_recipe(download=True)) if n_local else np.zeros(0, np.int32)
+        torch.cuda.synchronize()
+        cnt = torch.tensor([dtr, float(((st & 2) != 0).sum()), float(((st & 8) != 0).sum()), float(((st & 1) != 0).sum())],
+                           device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        if dist_on:
+            mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            dtr = float(mx[0])
+        recipe_line = {"beam": 6.0, "retry_beam": 40.0, "k1_cells": "khg_loglikes_reachable (no band)", "steps": 2, "ms_per_step": dtr / 2 * 1e3,
+                       "value": frames_total * 2 / dtr, "kernel_ms_per_step": {k: v / 2 for k, v in sorted(kr.items())},
+                       "retried_utts": int(cnt[1]), "fallback_decoder_utts": int(cnt[2]), "failed_utts": int(cnt[3]), "utterances": args.utts,
+                       "note": "the recipe's AlignConfig (egs/yesno/train.py:165-167) on the benchmark's set: retried = num_retried of "
+                               "decoder-wrappers.cc:68-75, fallback = utterances whose exact-DP beam certificate failed and that the order-"
+                               "faithful FasterDecoder kernel decoded; with the TRAINED-like synthetic model of this set (Gaussians ~27 sigma "
+                               "apart) the correct path wins by a wide margin, so few utterances leave the certified path -- "
+                               "tools/fallback_stress.py is the flat-start-like case (~45 % through the fallback)"}
+
     # what every rank did, so that imbalance between the shards is visible on the one line rank 0 prints
     mine_info = {"rank": rank, "utterances": n_local, "frames": frames_local, "seconds": dt_local,
                  "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())}}
@@ -680,9 +915,11 @@ def main():
             bflops = cells * (nprod * 4.0 * D * G + 5.0 * G)
             kname = {"f16x2s": "k1s_loglikes: v_mfma_f32_32x32x16_f16, f16x2s", "f16x2": "k1h_loglikes: v_mfma_f32_32x32x16_f16, f16x2",
                      "bf16x3": "k1b_loglikes: v_mfma_f32_32x32x16_bf16, bf16x3"}[k1_form]
-            roofline = {"bound": "mfma", "kernel": "k1_loglikes (%s)" % kname, "achieved": bflops / t_k1 / 1e12,
-                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bflops / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": "k1_loglikes (%s)" % kname,
                         "frac_executed": bflops * k1_exec_frac / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        "achieved": bflops * k1_exec_frac / t_k1 / 1e12,
+                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bflops * k1_exec_frac / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        "frac_dense_contract": bflops / t_k1 / 1e12 / PEAK_BF16_MFMA_TFLOPS, "achieved_dense_contract": bflops / t_k1 / 1e12,
                         "fp32_equivalent": {"achieved": k1_flops_per_launch / t_k1 / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                             "frac": k1_flops_per_launch / t_k1 / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                             "note": "the SURVEY 8(d) fp32 contract FLOPs (4DG + 5G per cell) over the same time, against the fp32-MFMA "
@@ -691,23 +928,57 @@ def main():
                         "executed_cell_fraction": k1_exec_frac,
                         "k1_cells": "band: per pdf from its first readable to its last useful 32-frame tile, the tiles starting at the band's first frame where that saves one (khg_loglikes_band)" if band else
                                     ("all" if args.full_loglikes else "from each pdf's first readable tile (khg_loglikes_reachable)"),
-                        "note": "achieved/frac: 16-bit FLOPs of the dense T x P_u contract (%d partial products per fp32 product) / kernel time "
-                                "/ the 2.5 PFLOP/s dense fp16 = bf16 peak; K1 evaluates only the cells a decoder token can read, in whole 32-frame "
-                                "tiles (executed_cell_fraction); frac_executed = frac x that fraction.  K1 is bound by POWER: under a bare "
+                        "note": "frac = frac_executed = achieved / peak: the 16-bit FLOPs of the cells K1 EXECUTES (%d partial products per fp32 "
+                                "product; what SQ_VALU_MFMA_BUSY shows) / kernel time / the 2.5 PFLOP/s dense fp16 = bf16 peak -- the utilisation.  "
+                                "frac_dense_contract credits the whole T x P_u contract of SURVEY 8(d), i.e. also the cells K1 skips because no "
+                                "decoder token can read them (executed_cell_fraction of the contract is executed, in whole 32-frame "
+                                "tiles): work avoided, not utilisation.  K1 is bound by POWER: under a bare "
                                 "dependent 16-bit MFMA loop the chip holds 1.5-1.8 GHz (18.7-21.5 ns per v_mfma_f32_32x32x16 and SIMD on the boxes "
                                 "of this pool, tools/k1lab.hip: 0.60-0.72 of the 2.5 PFLOP/s spec peak), and every byte moved and VALU "
                                 "instruction issued beside the MFMAs lowers the clock further" % nprod,
                         "kernel_ms": k1_avg_ms, "flops_per_launch": bflops, "launches_per_step": nb}
         else:
             ach = k1_flops_per_launch / t_k1 / 1e12
-            roofline = {"bound": "mfma", "kernel": "k1_loglikes (fp32 MFMA, %s)" % k1_form, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "frac_executed": ach * k1_exec_frac / PEAK_F32_MFMA_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": "k1_loglikes (fp32 MFMA, %s)" % k1_form, "frac_executed": ach * k1_exec_frac / PEAK_F32_MFMA_TFLOPS,
+                        "achieved": ach * k1_exec_frac, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach * k1_exec_frac / PEAK_F32_MFMA_TFLOPS, "frac_dense_contract": ach / PEAK_F32_MFMA_TFLOPS, "achieved_dense_contract": ach,
                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                         "executed_cell_fraction": k1_exec_frac,
-                        "note": "achieved/frac use the dense T x P_u contract FLOPs of SURVEY 8(d); K1 evaluates only the (frame, pdf) cells a "
-                                "decoder token can read, in whole 16-frame tiles (executed_cell_fraction of them); frac_executed = frac x "
-                                "executed_cell_fraction is the MFMA utilisation (what the SQ_VALU_MFMA_BUSY_CYCLES counter shows)",
+                        "note": "frac = frac_executed: the FLOPs of the (frame, pdf) cells K1 executes (those a decoder token can read, in whole "
+                                "16-frame tiles: executed_cell_fraction of the dense T x P_u contract of SURVEY 8(d)) -- the MFMA utilisation the "
+                                "SQ_VALU_MFMA_BUSY_CYCLES counter shows; frac_dense_contract credits the whole contract",
                         "kernel_ms": k1_avg_ms, "flops_per_launch": k1_flops_per_launch, "launches_per_step": nb}
+        # "K1 vs MFMA peak, K2 / K3 vs HBM peak, C1 vs 7 x 153 GB/s" -- the bandwidth-bound kernels by their ALGORITHMIC bytes
+        # per launch (what has to cross HBM once) over the HIP-event time of the launch, against 8 TB/s
+        PEAK_HBM_GBPS, PEAK_XGMI_GBPS = 8000.0, 7 * 153.0
+        S_u = np.diff(ut.graphs["state_off"]).astype(np.float64)
+        tpad = ((T + 31) // 32 * 32).astype(np.float64)
+        k2_bytes = float((npdf * tpad).sum()) * 4 + float((T * S_u).sum()) * 0.5 * 2 + float(T.sum()) * 4
+        sumG_ = float(model.gauss_off[-1])
+        k3_bytes = float(T.sum()) * (4.0 * D + 8.0) + sumG_ * (2 * D + 1) * (4.0 + 8.0)
+        kms = {k: v / args.steps for k, v in kernel_ms.items()}
+
+        def hbm(bytes_, ms):
+            return {"bytes": bytes_, "ms": ms, "GBps": bytes_ / (ms * 1e-3) / 1e9 if ms else None,
+                    "frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if ms else None}
+        roofline["kernels"] = {
+            "k2": dict(hbm(k2_bytes, kms.get("k2_viterbi_dp", 0.0)), kernel="k2_viterbi_dp",
+                       bytes_note="scores read once (4 B x listed pdfs x padded frames) + back-pointers written and read (a nibble per state and "
+                                  "frame, twice) + the alignment (4 B per frame)"),
+            "k3": dict(hbm(k3_bytes, kms.get("k3_accumulate", 0.0)), kernel="k3_accumulate",
+                       bytes_note="features gathered once (4 D B per frame) + alignment and frame ids (8 B per frame) + the model rows read and the "
+                                  "fp64 accumulator rows flushed once (12 B x (2 D + 1) per Gaussian)"),
+            "k3_bucket": dict(hbm(float(T.sum()) * (4.0 + 3 * 12.0), kms.get("k3_bucket", 0.0)), kernel="k3_sort_keys + radix sort + k3_bounds",
+                              bytes_note="alignment read (4 B) + key / value pairs written, sorted (one read + one write per pair) and read back"),
+        }
+        if dist_on and world > 1:
+            c1_ms = kms.get("c1_allreduce", 0.0)
+            blk = float(accs.size) * 8
+            bus = 2.0 * (world - 1) / world * blk
+            roofline["kernels"]["c1"] = {"bytes": blk, "ms_pipelined_pieces": c1_ms, "ms_alone": rccl_info["c1_ms_alone"] if rccl_info else None,
+                                         "busbw_GBps": bus / (rccl_info["c1_ms_alone"] * 1e-3) / 1e9 if rccl_info and rccl_info.get("c1_ms_alone") else None,
+                                         "frac_xgmi": bus / (rccl_info["c1_ms_alone"] * 1e-3) / 1e9 / PEAK_XGMI_GBPS if rccl_info and rccl_info.get("c1_ms_alone") else None,
+                                         "note": "ring all-reduce: 2 (N - 1) / N x block bytes leave every GPU; against 7 links x 153 GB/s"}
         out = {
             "metric": "frames/sec (whole node) per EM iter (align+acc-stats), 5k-pdf x 64-Gauss",
             "value": frames_total * args.steps / dt,
@@ -747,8 +1018,10 @@ def main():
             "fp32_mfma_line": fp32_line,
             "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())},
             "prep_ms": {"kernels": prep_ms, "total": sum(prep_ms.values()),
-                        "note": "once per utterance set (column maxima, fp16 feature planes) / per parameter version (fp16 model image): "
-                                "outside the timed region, measured during the first warm-up step"},
+                        "note": "once per UTTERANCE SET (the features' column maxima -- k1_absmax here also covers the model's columns of the "
+                                "first step --, the fp16 feature planes): outside the timed region, measured during the first warm-up step.  What "
+                                "is derived per PARAMETER VERSION (k0_model_stats: column maxima, feature envelope, band upper bounds in one pass; k0s_pack_tiles) is INSIDE "
+                                "every timed step since round 5 (khg_model_invalidate at the top of the step) and listed in kernel_ms_per_step"},
             "allreduce_ms_per_step": (sum(a_.elapsed_time(b_) for a_, b_ in ar_events) / max(len(ar_events), 1)) if ar_events else None,
             "allreduce_bytes": int(accs.size) * 8 if dist_on else None,
             "m_step": m_step,
@@ -756,7 +1029,11 @@ def main():
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
             "allreduce": args.allreduce if dist_on else None,
             "rccl": rccl_info,
-            "scaling_efficiency_vs_n1_shard": shard_efficiency(args, world, per_rank, kernel_ms),
+            "scaling_efficiency_vs_n1_shard": None if alone_ms is None else {
+                "value": alone_ms / (dt / args.steps * 1e3), "shards_without_exchange_ms_per_step": alone_ms, "ms_per_step": dt / args.steps * 1e3,
+                "note": "measured in THIS run: two extra steps with every rank alone on its shard (no C1), slowest rank, over the timed "
+                        "ms_per_step -- 1.0 = the exchange is fully hidden; what is left of the N-fold speed-up besides this is the small-shard "
+                        "effect (fewer, shorter launches per kernel), visible as N x shards_without_exchange_ms_per_step against the N = 1 line"},
             "c1_pipelined_parts": args.c1_parts if (dist_on and args.allreduce == "khg" and args.c1_parts > 1 and len(streams) == 1) else None,
             "per_rank": per_rank if world > 1 else None,
         }
@@ -772,6 +1049,9 @@ def main():
             out["check"].update(check_vs_oracle(ans, ut, feats, D, sets, ctxs[0], model, gc, tm, args))
         else:
             out["cpu_baseline"] = None
+        out["recipe_beam_line"] = recipe_line
+        if args.per_call_utts > 0:
+            out["per_call_line"] = per_call_line(args, model, ut, feats, D, ctxs[0], out.get("cpu_baseline"))
         record = json.dumps(out)
     if dist_on:
         dist.barrier()

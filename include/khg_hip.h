@@ -117,6 +117,12 @@ int khg_model_create(khg_ctx *ctx, int32_t num_pdfs, int32_t dim, const int32_t 
                      const float *gconsts_h, const float *means_invvars_h,
                      const float *inv_vars_h, khg_model **out);
 int khg_model_destroy(khg_model *m);
+/* Measurement / consistency aid: drops what the handle caches PER PARAMETER VERSION -- the fp16 / bf16 K1 images, the BAND form's
+ * per-pdf upper bounds, the column maxima and scale exponents -- as every in-place update (khg_model_mle_update, _split, _merge,
+ * _scale_weights) does, without touching the parameters: the next khg_loglikes / khg_acc_stats derive them again.  One EM iteration of
+ * the reference changes the parameters once (scripts/gmm_est.py:8-96), so a benchmark step that is to pay what a real iteration
+ * pays calls this once per step (bench.py). */
+int khg_model_invalidate(khg_model *m);
 
 /* ---- transition information ------------------------------------------------------------ */
 /* TransitionInformation::TransitionIdToPdf table (csrc/transition-information.h:71-73,
@@ -169,8 +175,10 @@ int khg_loglikes_reachable(khg_ctx *ctx, const khg_model *m, khg_utts *u);
  * to a final state, khg_utts_pdf_last).  Those cells are FILLED with an upper bound of the pdf's log-likelihood, so the exact DP
  * of khg_align sees such tokens at costs no higher than the reference decoder would -- its beam certificate stays sound and the
  * best path is untouched.  An utterance whose certificate fails is recomputed without the band by khg_align itself before the
- * order-faithful decoder reads it (the model handle must stay alive, unchanged, until that khg_align returns): alignments are
- * identical to khg_loglikes + khg_align at any beam.  Worth it when the beam is wide (few certificates fail): ~21 % fewer cells at
+ * order-faithful decoder reads it: EVERY khg_align on these scores needs the model handle alive and at the parameter version the scores
+ * were computed with -- a handle destroyed or updated in between makes khg_align return KHG_E_ARG (checked by handle serial and
+ * version, never by dereferencing a stale pointer); a handle whose fp16 image was merely re-packed for another set's feature
+ * exponents makes khg_align score the set again first.  Alignments are identical to khg_loglikes + khg_align at any beam.  Worth it when the beam is wide (few certificates fail): ~21 % fewer cells at
  * the benchmark's shape.  Cells of a pdf BEFORE its first readable frame are unspecified (as with khg_loglikes_reachable, here to
  * the frame: a band's 32-frame tiles may start at that frame instead of on the 32-frame grid).  Default K1 form only (f16x2s, pdfs
  * of more than 16 Gaussians); anything else: khg_loglikes_reachable. */

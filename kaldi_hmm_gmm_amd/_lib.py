@@ -145,6 +145,7 @@ SIGNATURES = {
     "khg_model_split": (C.c_int, [vp, vp, c_i32p, C.c_float, c_f32p, C.c_int64]),
     "khg_model_merge": (C.c_int, [vp, vp, c_i32p]),
     "khg_model_num_gauss": (C.c_int, [vp, C.POINTER(C.c_int64), c_i32p]),
+    "khg_model_invalidate": (C.c_int, [vp]),
     "khg_model_download": (C.c_int, [vp, vp, c_f32p, c_f32p, c_f32p, c_f32p]),
     "khg_accs_relayout": (C.c_int, [vp, vp, vp]),
     "khg_accs_download_trans": (C.c_int, [vp, vp, c_f64p, c_f64p]),

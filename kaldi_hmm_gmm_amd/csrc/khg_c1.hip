@@ -160,12 +160,12 @@ extern "C" int khg_accs_allreduce_f32(khg_ctx* ctx, khg_accs* a, void* comm) {
   }
   KernelTimer kt(ctx, "c1_allreduce_f32");
   const int gb = (int)std::min<int64_t>(8192, (a->n + 255) / 256);
-  hipLaunchKernelGGL(c1_narrow, dim3(gb), dim3(256), 0, ctx->stream, a->buf_d, a->wire_d, a->n);
+  KHG_LAUNCH(ctx, c1_narrow, dim3(gb), dim3(256), 0, ctx->stream, a->buf_d, a->wire_d, a->n);
   if (comm) {
     int r = g_rccl.AllReduce(a->wire_d, a->wire_d, (size_t)a->n, kNcclFloat32, kNcclSum, comm, ctx->stream);
     if (r) return rccl_fail("ncclAllReduce", r);
   }
-  hipLaunchKernelGGL(c1_widen, dim3(gb), dim3(256), 0, ctx->stream, a->wire_d, a->buf_d, a->n);
+  KHG_LAUNCH(ctx, c1_widen, dim3(gb), dim3(256), 0, ctx->stream, a->wire_d, a->buf_d, a->n);
   HIPCHK(hipGetLastError());
   return KHG_OK;
 }

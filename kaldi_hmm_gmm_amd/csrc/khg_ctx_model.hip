@@ -51,6 +51,10 @@ int arena_flush(khg_ctx* ctx) {
   a.dirty.clear();
   return KHG_OK;
 }
+bool khg_ctx_alive(const khg_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return std::find(g_ctxs.begin(), g_ctxs.end(), ctx) != g_ctxs.end();
+}
 bool khg_arena_release(void* p) {
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   for (khg_ctx* c : g_ctxs) {
@@ -243,6 +247,134 @@ __global__ void k0_nhalf(const float* __restrict__ iv, int64_t n, float* __restr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) nhiv[i] = -0.5f * iv[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// What the library derives from the parameters once per PARAMETER VERSION, in ONE pass over the model's rows (round 5; four passes --
+// three k1h_absmax launches and k3_model_xbound, each with its own scratch, download and wait -- plus k1s_ubound before):
+//   maxima[0 .. D)          max |means_invvars[.][d]|      } the column maxima behind the split K1 forms' scale exponents and
+//   maxima[512 .. 512 + D)  max |inv_vars[.][d]|           } domain checks (k1h_absmax's rule: -inf skipped, NaN / inf -> +inf)
+//   maxima[1024 .. 1024+D)  max_g |mean| + 8 sigma         the feature envelope K3's fp16 phase A scales by (k3_model_xbound's rule)
+//   maxima[1536]            max |gconst|
+//   ubound[first tile of p] log sum_g exp(gconst_g + 0.5 sum_d mi^2 / iv) + margin: the BAND form's fill (k1s_ubound's rule, fp64,
+//                           every sum in a fixed order: the value does not depend on the launch)
+// One workgroup walks pdfs p = block, block + grid, ...; a thread owns one dimension of one of the 256 / D rows of a pass (two
+// dimensions when D > 256); a row's fp64 terms are summed by its first thread, a pdf's components by wave 0.
+struct K0StatsArgs {
+  const float *gconsts, *miv, *iv;
+  const int32_t *gauss_off, *pdf_tile_off;     // pdf_tile_off / ubound may be NULL (no tile image: D > 80)
+  int P, D;
+  uint32_t* maxima;                            // [1537], zeroed by the caller
+  float* ubound;
+};
+__device__ __forceinline__ float k0_absmax_step(float m, float v) {
+  if (v == -INFINITY) return m;
+  return (fabsf(v) <= 3.0e38f) ? fmaxf(m, fabsf(v)) : INFINITY;
+}
+__global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
+  __shared__ double s_term[256];
+  __shared__ double s_c[1024];
+  const int D = a.D, Dc = D < 256 ? D : 256, RP = 256 / Dc, t = threadIdx.x;
+  const int r = t / Dc, d0 = t - r * Dc;
+  const bool act = r < RP;
+  float m_miv[2] = {0.0f, 0.0f}, m_iv[2] = {0.0f, 0.0f}, m_xb[2] = {0.0f, 0.0f}, m_gc = 0.0f;
+  for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+    const int g0 = a.gauss_off[p], g1 = a.gauss_off[p + 1];
+    double lm = -INFINITY, ls = 0.0;             // wave 0's per-lane running (max, sum) over this pdf's components
+    for (int gb = g0; gb < g1; gb += 1024) {     // <= 1024 components at a time through s_c
+      const int ge = min(g1, gb + 1024);
+      for (int g = gb; g < ge; g += RP) {
+        double term = 0.0;
+        const int row = g + r;
+        if (act && row < ge) {
+          int j = 0;
+          for (int d = d0; d < D; d += Dc, ++j) {
+            const float mi = a.miv[(size_t)row * D + d], v = a.iv[(size_t)row * D + d];
+            m_miv[j] = k0_absmax_step(m_miv[j], mi);
+            m_iv[j] = k0_absmax_step(m_iv[j], v);
+            float b = fabsf(mi / v) + 8.0f * rsqrtf(v);
+            if (!(b < 3.0e38f)) b = INFINITY;
+            m_xb[j] = fmaxf(m_xb[j], b);
+            term += 0.5 * (double)mi * (double)mi / (double)v;
+          }
+          if (d0 == 0) m_gc = k0_absmax_step(m_gc, a.gconsts[row]);
+        }
+        s_term[t] = term;
+        __syncthreads();
+        if (act && d0 == 0 && row < ge) {
+          double c = 0.0;
+          for (int k = 0; k < Dc; ++k) c += s_term[r * Dc + k];
+          s_c[row - gb] = c + (double)a.gconsts[row];
+        }
+        __syncthreads();
+      }
+      if (t < 64) {
+        for (int i = t; i < ge - gb; i += 64) {
+          const double c = s_c[i];
+          if (c > lm) { ls = ls * exp(lm - c) + 1.0; lm = c; }
+          else if (c > -INFINITY) ls += exp(c - lm);
+        }
+      }
+      __syncthreads();
+    }
+    if (t < 64 && a.ubound && a.pdf_tile_off) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_xor(lm, o), s2 = __shfl_xor(ls, o);
+        const double mm = fmax(lm, m2);
+        if (mm > -INFINITY) ls = ls * exp(lm - mm) + s2 * exp(m2 - mm);
+        lm = mm;
+      }
+      if (t == 0 && a.pdf_tile_off[p + 1] > a.pdf_tile_off[p]) {
+        double v = lm + log(ls);
+        if (!(v == v) || v == -INFINITY) v = 0.0;         // an all-dead pdf scores -inf everywhere (an error in K1 either way): any finite fill
+        if (v > 3.0e38) v = 3.0e38;
+        float vf = (float)v;
+        if ((double)vf < v) vf = nextafterf(vf, INFINITY);        // rounded up: still a bound
+        a.ubound[a.pdf_tile_off[p]] = vf + 1.0e-3f + 1.0e-5f * fabsf(vf);
+      }
+    }
+  }
+  if (act) {
+    int j = 0;
+    for (int d = d0; d < D; d += Dc, ++j) {
+      if (m_miv[j] > 0.0f) atomicMax(a.maxima + d, __float_as_uint(m_miv[j]));
+      if (m_iv[j] > 0.0f) atomicMax(a.maxima + 512 + d, __float_as_uint(m_iv[j]));
+      if (m_xb[j] > 0.0f) atomicMax(a.maxima + 1024 + d, __float_as_uint(m_xb[j]));
+    }
+    if (d0 == 0 && m_gc > 0.0f) atomicMax(a.maxima + 1536, __float_as_uint(m_gc));
+  }
+}
+
+// The host side: runs once per parameter version (wmax empty = stale), fills wmax / gcmax (K1's column maxima), k3_xb (K3's feature
+// envelope; the exponents derived from it stay in khg_k3.hip) and, where the model has a tile layout, ubound.
+int model_stats(khg_ctx* ctx, khg_model* m) {
+  if (!m->wmax.empty()) return KHG_OK;
+  const int D = m->D, K = m->KS > 0 ? 16 * m->KS : 2 * D;
+  if (!m->stats_d) { int rc = dev_alloc(&m->stats_d, 1537); if (rc) return rc; }
+  if (m->KQ != 0 && (!m->ubound_d || m->ubound_tiles < m->ntiles)) {
+    DEVFREE(m->ubound_d);
+    int rc = dev_alloc(&m->ubound_d, (size_t)m->ntiles);
+    if (rc) return rc;
+    m->ubound_tiles = m->ntiles;
+  }
+  HIPCHK(hipMemsetAsync(m->stats_d, 0, 1537 * sizeof(uint32_t), ctx->stream));
+  K0StatsArgs a{m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->KQ != 0 ? m->pdf_tile_off_d : nullptr, m->P, D, m->stats_d, m->KQ != 0 ? m->ubound_d : nullptr};
+  {
+    KernelTimer kt(ctx, "k0_model_stats");
+    KHG_LAUNCH(ctx, k0_model_stats, dim3((unsigned)std::min(m->P, 2048)), dim3(256), 0, ctx->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  std::vector<uint32_t> h(1537);
+  HIPCHK(hipMemcpyAsync(h.data(), m->stats_d, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  auto f = [&](size_t i) { float v; memcpy(&v, &h[i], sizeof(float)); return v; };
+  m->wmax.assign((size_t)std::max(K, 2 * D), 0.0f);
+  for (int d = 0; d < D; ++d) { m->wmax[(size_t)2 * d] = f((size_t)d); m->wmax[(size_t)2 * d + 1] = 0.5f * f(512 + (size_t)d); }
+  m->gcmax = f(1536);
+  m->k3_xb_raw.assign((size_t)D, 0.0f);
+  for (int d = 0; d < D; ++d) m->k3_xb_raw[(size_t)d] = f(1024 + (size_t)d);
+  m->ubound_valid = m->KQ != 0;
+  return KHG_OK;
+}
+
 // (Re)build everything derived from gauss_off + the row-major parameters in HBM: the tile offsets, the K1
 // tile image and the -0.5*inv_vars copy K3 reads -- packed ON THE DEVICE (k0_pack_tiles), no host-side
 // 113 MB image, no extra copies.  Used by khg_model_create and after the device M-step.
@@ -266,7 +398,7 @@ int model_pack(khg_ctx* ctx, khg_model* m) {
     m->wimgb_valid = false;
     m->wimgh_ex.clear(); m->wimgs_key.clear(); m->ubound_valid = false; m->wmax.clear(); m->k3_xb.clear();
     const int64_t n = m->sumG * D;
-    hipLaunchKernelGGL(k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
+    KHG_LAUNCH(ctx, k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
@@ -291,8 +423,8 @@ int model_pack(khg_ctx* ctx, khg_model* m) {
   int32_t* tile_pdf_d = m->tile_pdf_d;
   if (!rc) {
     KernelTimer kt(ctx, "k0_pack_tiles");
-    if (m->KQ == 10) hipLaunchKernelGGL(k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
-    else hipLaunchKernelGGL(k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+    if (m->KQ == 10) KHG_LAUNCH(ctx, k0_pack_tiles<10>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
+    else KHG_LAUNCH(ctx, k0_pack_tiles<20>, dim3(nt), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, tile_pdf_d, D, m->wimg_d, m->nhiv_d);
   }
   if (!rc) {
     hipError_t e = hipGetLastError();
@@ -342,11 +474,21 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
   *out = m;
   return KHG_OK;
 }
+// Everything derived from the parameters and cached per parameter version (the split K1 forms' images and their keys, the BAND form's
+// upper bounds, the column maxima behind the scale exponents, K3's phase-A scales) is dropped and the version moves on, exactly as
+// after an in-place update: the next khg_loglikes / khg_acc_stats derive them again.
+extern "C" int khg_model_invalidate(khg_model* m) {
+  if (!m) return khg_set_error(KHG_E_ARG, "khg_model_invalidate: model is NULL");
+  ++m->version;
+  m->wimgb_valid = false;
+  m->wimgh_ex.clear(); m->wimgs_key.clear(); m->ubound_valid = false; m->wmax.clear(); m->k3_xb.clear();
+  return KHG_OK;
+}
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   { std::lock_guard<std::mutex> lk(g_model_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
   m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->stats_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;

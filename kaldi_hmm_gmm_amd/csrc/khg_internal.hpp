@@ -70,6 +70,9 @@ void* arena_alloc(khg_ctx* ctx, size_t bytes);             // 256-byte aligned; 
 bool khg_arena_release(void* p);                           // true when p came from some context's arena
 void khg_dev_free(void* p);                                // arena or hipFree
 void arena_mark_dirty(khg_ctx* ctx, const void* dev_ptr, size_t bytes);
+bool khg_ctx_alive(const khg_ctx* ctx);                    // khg_ctx_model.hip: the context has not been destroyed (handles may outlive it)
+// Every kernel launch of the library goes through this: uploads staged in the arena since the last launch reach the device first.
+#define KHG_LAUNCH(ctx_, ...) do { (void)arena_flush(ctx_); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled); staged uploads go out first
 struct KernelTimer {
   khg_ctx* c; size_t idx = 0; bool on; hipStream_t s;
@@ -180,6 +183,8 @@ struct khg_model {
   std::vector<float> wmax;         // per k = 2 d + kind: max |W[.][k]| of the current parameters (empty: not computed)
   // K3's fp16 phase A (k3_accumulate_wave<NB, true>): scale exponents derived from the model alone; cleared with wmax
   std::vector<float> k3_xb;        // per dim: max over the Gaussians of |mean| + 8 sigma (empty: not computed)
+  std::vector<float> k3_xb_raw;    // the same as model_stats read it (valid with wmax); k3_xb / k3_ex / k3_S are derived from it in khg_k3.hip
+  uint32_t* stats_d = nullptr;     // landing block of k0_model_stats
   std::vector<int32_t> k3_ex;      // [80] per k = 2 d + kind
   int32_t k3_S = 0;
   bool k3_f16_ok = false;          // the model side of the form's domain holds
@@ -310,6 +315,7 @@ inline int u_upload(khg_ctx* ctx, khg_utts* u, T** p, const std::vector<T>& v) {
 // ---- functions one unit calls in another ---------------------------------------------------------------------------------
 int check_err_flag(khg_ctx* c, const char* where);        // khg_ctx_model.hip: read-and-clear the device error word (synchronises)
 int model_pack(khg_ctx* ctx, khg_model* m);               // khg_ctx_model.hip: everything derived from gauss_off + the row-major parameters
+int model_stats(khg_ctx* ctx, khg_model* m);              // khg_ctx_model.hip: per parameter version, one pass: column maxima, feature envelope, band upper bounds
 int wait_ali(khg_ctx* ctx, khg_utts* u);                  // khg_utts.hip: the main stream waits for the side-stream decoder
 void k1_free_band(khg_utts* u);                           // khg_k1.hip: the BAND form's saved launch arguments
 int k1_maxima(khg_ctx* ctx, khg_model* m, khg_utts* u, std::vector<float>* xk);   // khg_k1.hip: column maxima of features / parameters

@@ -12,9 +12,9 @@
 // ------------------------------------------------------------------------------------------
 // K1
 template <int KQ, int NF, int WPS>
-static void launch_k1(const K1Args& a, int nchunks, bool aligned, hipStream_t s) {
-  if (aligned) hipLaunchKernelGGL((k1_loglikes<KQ, NF, true, WPS>), dim3(nchunks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
+static void launch_k1(khg_ctx* ctx, const K1Args& a, int nchunks, bool aligned, hipStream_t s) {
+  if (aligned) KHG_LAUNCH(ctx, (k1_loglikes<KQ, NF, true, WPS>), dim3(nchunks), dim3(256), 0, s, a);
+  else KHG_LAUNCH(ctx, (k1_loglikes<KQ, NF, false, WPS>), dim3(nchunks), dim3(256), 0, s, a);
 }
 // 16-frame tiles per wave: 6 x 20 B-operand VGPRs fit 2 waves/SIMD at D <= 40 (KHG_K1_NF=5 selects the smaller chunk)
 static int k1_nf(const khg_ctx* ctx, int KQ) { return KQ != 10 ? 5 : ctx->opt[KHG_OPT_K1_NF] == 5 ? 5 : 6; }
@@ -42,7 +42,7 @@ static int loglikes_wide(khg_ctx* ctx, const khg_model* m, khg_utts* u) {
   if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k1w_loglikes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (u->n_wchunks > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
-    hipLaunchKernelGGL(k1w_loglikes, dim3(u->n_wchunks), dim3(256), lds, ctx->stream, a);
+    KHG_LAUNCH(ctx, k1w_loglikes, dim3(u->n_wchunks), dim3(256), lds, ctx->stream, a);
   }
   HIPCHK(hipGetLastError());
   u->ll_valid = true;
@@ -67,8 +67,8 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
     if (!rc) rc = u_alloc(u, &u->xpl_d, (size_t)std::max<int64_t>(nx, 1) * 2 * 16 * KH);
     if (!rc && nx > 0) {
       const int gb = (int)std::min<int64_t>(65535, (nx * (2 * 16 * KH / 4) + 255) / 256);
-      if (m->KQ == 10) hipLaunchKernelGGL(k1p_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
-      else hipLaunchKernelGGL(k1p_pack_x<20>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
+      if (m->KQ == 10) KHG_LAUNCH(ctx, k1p_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
+      else KHG_LAUNCH(ctx, k1p_pack_x<20>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_xtile_off_d, xutt_d, nx, u->D, u->xpl_d);
       hipError_t e = hipGetLastError();
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
@@ -146,7 +146,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
       if (n == 0) continue;
       a.slice0 = first;
       first += n;
-#define K1P_LAUNCH(KQ_, NB_, WPS_) hipLaunchKernelGGL((k1p_loglikes<KQ_, NB_, WPS_>), dim3(n), dim3(256), 0, ctx->stream, a)
+#define K1P_LAUNCH(KQ_, NB_, WPS_) KHG_LAUNCH(ctx, (k1p_loglikes<KQ_, NB_, WPS_>), dim3(n), dim3(256), 0, ctx->stream, a)
       if (m->KQ == 10) {
         switch (nb) { case 1: K1P_LAUNCH(10, 1, 2); break; case 2: K1P_LAUNCH(10, 2, 2); break; case 3: K1P_LAUNCH(10, 3, 2); break; case 4: K1P_LAUNCH(10, 4, 2); break;
                       case 5: K1P_LAUNCH(10, 5, 2); break; case 6: K1P_LAUNCH(10, 6, 2); break; case 7: K1P_LAUNCH(10, 7, 2); break; default: K1P_LAUNCH(10, 8, 2); break; }
@@ -258,8 +258,8 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool 
     rc = m->wimgb_sync.before_pack(ctx->stream);
     if (rc) return rc;
     KernelTimer kt(ctx, "k0b_pack_tiles");
-    if (KS == 5) hipLaunchKernelGGL(k0b_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
-    else hipLaunchKernelGGL(k0b_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
+    if (KS == 5) KHG_LAUNCH(ctx, k0b_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
+    else KHG_LAUNCH(ctx, k0b_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
     HIPCHK(hipGetLastError());
     rc = m->wimgb_sync.after_pack(ctx->stream);
     if (rc) return rc;
@@ -271,8 +271,8 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool 
     rc = u_alloc(u, &u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
     if (!rc && nx > 0) {
       const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
-      if (KS == 5) hipLaunchKernelGGL(k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
-      else hipLaunchKernelGGL(k1b_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
+      if (KS == 5) KHG_LAUNCH(ctx, k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
+      else KHG_LAUNCH(ctx, k1b_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
     }
@@ -294,8 +294,8 @@ static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool 
     if (rc) return rc;
     {
       KernelTimer kt(ctx, "k1_loglikes");
-      if (KS == 5) hipLaunchKernelGGL((k1b_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-      else hipLaunchKernelGGL((k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+      if (KS == 5) KHG_LAUNCH(ctx, (k1b_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+      else KHG_LAUNCH(ctx, (k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
     rc = m->wimgb_sync.after_read(ctx->stream);
@@ -315,7 +315,7 @@ static int absmax_cols(khg_ctx* ctx, const float* a_d, int64_t n, int D, std::ve
   if (e == hipSuccess && n > 0) {
     const int gb = (int)std::min<int64_t>(4096, (n + 1) / 2);
     KernelTimer kt(ctx, "k1_absmax");
-    hipLaunchKernelGGL(k1h_absmax, dim3(gb), dim3(256), 0, ctx->stream, a_d, n, D, m_d);
+    KHG_LAUNCH(ctx, k1h_absmax, dim3(gb), dim3(256), 0, ctx->stream, a_d, n, D, m_d);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), m_d, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
@@ -354,16 +354,7 @@ int k1_maxima(khg_ctx* ctx, khg_model* m, khg_utts* u, std::vector<float>* xk) {
   const int D = m->D, K = 16 * m->KS;
   int rc = KHG_OK;
   if (u->xmax.empty()) { rc = absmax_cols(ctx, u->feats_d, u->N, D, &u->xmax); if (rc) return rc; }
-  if (m->wmax.empty()) {
-    std::vector<float> a, b, g;
-    rc = absmax_cols(ctx, m->miv_d, m->sumG, D, &a);
-    if (!rc) rc = absmax_cols(ctx, m->iv_d, m->sumG, D, &b);
-    if (!rc) rc = absmax_cols(ctx, m->gconsts_d, m->sumG, 1, &g);
-    if (rc) return rc;
-    m->wmax.assign((size_t)K, 0.0f);
-    for (int d = 0; d < D; ++d) { m->wmax[(size_t)2 * d] = a[(size_t)d]; m->wmax[(size_t)2 * d + 1] = 0.5f * b[(size_t)d]; }
-    m->gcmax = g[0];
-  }
+  if (m->wmax.empty()) { rc = model_stats(ctx, m); if (rc) return rc; }      // one pass per parameter version (khg_ctx_model.hip)
   xk->assign((size_t)K, 0.0f);
   for (int d = 0; d < D; ++d) { (*xk)[(size_t)2 * d] = u->xmax[(size_t)d]; (*xk)[(size_t)2 * d + 1] = u->xmax[(size_t)d] * u->xmax[(size_t)d]; }
   return KHG_OK;
@@ -407,8 +398,8 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
     if (nx > 0) {
       KernelTimer kt(ctx, "k1h_pack_x");
       const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
-      if (KS == 5) hipLaunchKernelGGL(k1h_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
-      else hipLaunchKernelGGL(k1h_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
+      if (KS == 5) KHG_LAUNCH(ctx, k1h_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
+      else KHG_LAUNCH(ctx, k1h_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xh_ex_d, u->xh_d);
       HIPCHK(hipGetLastError());
     }
     { int rs = sync_pageable(ctx); if (rs) return rs; }    // `ex` (pageable) is free after this
@@ -424,8 +415,8 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
     rc = m->wimgh_sync.before_pack(ctx->stream);
     if (rc) return rc;
     KernelTimer kt(ctx, "k0h_pack_tiles");
-    if (KS == 5) hipLaunchKernelGGL(k0h_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
-    else hipLaunchKernelGGL(k0h_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
+    if (KS == 5) KHG_LAUNCH(ctx, k0h_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
+    else KHG_LAUNCH(ctx, k0h_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, u->xh_ex_d, m->wimgh_d);
     HIPCHK(hipGetLastError());
     rc = m->wimgh_sync.after_pack(ctx->stream);
     if (rc) return rc;
@@ -456,8 +447,8 @@ static int loglikes_f16x2(khg_ctx* ctx, khg_model* m, khg_utts* u, bool reachabl
     if (rc) return rc;
     {
       KernelTimer kt(ctx, "k1_loglikes");
-      if (KS == 5) hipLaunchKernelGGL((k1h_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-      else hipLaunchKernelGGL((k1h_loglikes<10, K1H_NT10>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+      if (KS == 5) KHG_LAUNCH(ctx, (k1h_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
+      else KHG_LAUNCH(ctx, (k1h_loglikes<10, K1H_NT10>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
     rc = m->wimgh_sync.after_read(ctx->stream);
@@ -502,29 +493,39 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
   // exponents, so per-set exponents would re-pack the 100 MB image on every alternating call.  The model keeps the element-wise
   // minimum of the exponents of the sets it has scored (a smaller exponent never overflows fp16; the absolute part of the error
   // bound is re-checked below for the exponents actually used) and every set packs its planes with those.
-  if (m->xs_ex_seen.size() == ex.size()) {
-    for (int k = 0; k < K; ++k) ex[(size_t)k] = std::min(ex[(size_t)k], m->xs_ex_seen[(size_t)k]);
+  // (When the shared exponents push the absolute part of the error bound past its limit -- a set with far larger features scored
+  //  against this model earlier -- and the set's OWN exponents hold it, the model follows this set: one re-pack instead of the
+  //  slower two-accumulator form for every set from here on.)
+  const std::vector<int32_t> ex_own = ex;
+  int S = 0;
+  auto scales = [&]() -> bool {         // S, ew and the floor for the current `ex`
+    S = INT_MAX;
+    for (int k = 0; k < K; ++k) if (m->wmax[(size_t)k] > 0.0f) S = std::min(S, 14 - std::ilogb(m->wmax[(size_t)k]) + ex[(size_t)k]);
+    if (S == INT_MAX) S = 0;
+    if (S < -100 || S > 100) return false;
+    double floor_sum = 0.0;      // the absolute part of the error bound, at the column maxima (khg_k1_f16x2s.hip.inc)
+    for (int k = 0; k < K; ++k) {
+      ew[(size_t)k] = S - ex[(size_t)k];
+      floor_sum += std::ldexp((double)m->wmax[(size_t)k], ew[(size_t)k]) + std::ldexp((double)xk[(size_t)k], ex[(size_t)k]);
+    }
+    return std::ldexp(floor_sum, -25 - S) <= 2.0e-6;
+  };
+  bool shared = m->xs_ex_seen.size() == ex.size();
+  if (shared) for (int k = 0; k < K; ++k) ex[(size_t)k] = std::min(ex[(size_t)k], m->xs_ex_seen[(size_t)k]);
+  if (!scales()) {
+    if (!shared || ex == ex_own) return 1;
+    ex = ex_own;
+    if (!scales()) return 1;
   }
   m->xs_ex_seen = ex;
-  int S = INT_MAX;
-  for (int k = 0; k < K; ++k) if (m->wmax[(size_t)k] > 0.0f) S = std::min(S, 14 - std::ilogb(m->wmax[(size_t)k]) + ex[(size_t)k]);
-  if (S == INT_MAX) S = 0;
-  if (S < -100 || S > 100) return 1;
-  double floor_sum = 0.0;      // the absolute part of the error bound, at the column maxima (khg_k1_f16x2s.hip.inc)
-  for (int k = 0; k < K; ++k) {
-    ew[(size_t)k] = S - ex[(size_t)k];
-    floor_sum += std::ldexp((double)m->wmax[(size_t)k], ew[(size_t)k]) + std::ldexp((double)xk[(size_t)k], ex[(size_t)k]);
-  }
-  floor_sum = std::ldexp(floor_sum, -25 - S);
-  if (!(floor_sum <= 2.0e-6)) return 1;
   rc = ensure_x32_layout(ctx, u);
   if (rc) return rc;
   if (!u->schunks_d || u->schunk_nmax != NMAX) {
     DEVFREE(u->schunks_d);
     std::vector<K1sChunk> ch;
-    // (a set of a few utterances cannot fill the chip with whole utterances: short chunks spread it over more workgroups -- the W
-    //  tiles are re-read per chunk from the cache, a band that crosses chunks keeps its aligned tiles)
-    plan_x32_chunks(u, u->small ? std::min(NMAX, 3) : NMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
+    // (one or two utterances -- the per-utterance call pattern -- cannot fill the chip with whole utterances: short chunks spread them
+    //  over more workgroups; the W tiles are re-read per chunk from the cache, a band that crosses chunks keeps its aligned tiles)
+    plan_x32_chunks(u, (u->small && u->n_utt <= 2) ? std::min(NMAX, 3) : NMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
     rc = u_upload(ctx, u, &u->schunks_d, ch);
     if (rc) return rc;
     { int rs = sync_pageable(ctx); if (rs) return rs; }
@@ -544,8 +545,8 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     if (nx > 0) {
       KernelTimer kt(ctx, "k1s_pack_x");
       const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
-      if (KS == 5) hipLaunchKernelGGL(k1s_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
-      else hipLaunchKernelGGL(k1s_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
+      if (KS == 5) KHG_LAUNCH(ctx, k1s_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
+      else KHG_LAUNCH(ctx, k1s_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, D, u->xs_ex_d, u->xs_d);
       HIPCHK(hipGetLastError());
     }
     { int rs = sync_pageable(ctx); if (rs) return rs; }    // `ex` (pageable) is free after this
@@ -570,8 +571,8 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     const float gscale = std::ldexp(1.0f, S);
     {
       KernelTimer kt(ctx, "k0s_pack_tiles");
-      if (KS == 5) hipLaunchKernelGGL(k0s_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, ew_d, gscale, m->wimgs_d);
-      else hipLaunchKernelGGL(k0s_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, ew_d, gscale, m->wimgs_d);
+      if (KS == 5) KHG_LAUNCH(ctx, k0s_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, ew_d, gscale, m->wimgs_d);
+      else KHG_LAUNCH(ctx, k0s_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, D, ew_d, gscale, m->wimgs_d);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // `ew` (pageable) and ew_d are free after this
@@ -627,16 +628,10 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     u->sunits_reach = units_key;
   }
   // BAND form: the per-pdf upper bounds the skipped tiles are filled with, indexed by a pdf's first W tile; per parameter version
-  if ((band || tail_shift) && !m->ubound_valid) {
-    if (!m->ubound_d || m->ubound_tiles < m->ntiles) {
-      DEVFREE(m->ubound_d);
-      rc = dev_alloc(&m->ubound_d, (size_t)m->ntiles);
-      if (rc) return rc;
-      m->ubound_tiles = m->ntiles;
-    }
-    hipLaunchKernelGGL(k1s_ubound, dim3(m->P), dim3(64), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, D, m->ubound_d);
-    HIPCHK(hipGetLastError());
-    m->ubound_valid = true;
+  if ((band || tail_shift) && !m->ubound_valid) {       // (filled by model_stats with the column maxima; only a stale flag gets here)
+    m->wmax.clear();
+    rc = model_stats(ctx, m);
+    if (rc) return rc;
   }
   K1sArgs a;
   a.xs = u->xs_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->schunks_d;
@@ -661,10 +656,10 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
       KernelTimer kt(ctx, "k1_loglikes");
-      if (pack == 4) hipLaunchKernelGGL((k1s_loglikes_packed<5, 4>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
-      else if (pack == 2) hipLaunchKernelGGL((k1s_loglikes_packed<5, 2>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
-      else if (KS == 5) hipLaunchKernelGGL((k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
-      else hipLaunchKernelGGL((k1s_loglikes<10>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      if (pack == 4) KHG_LAUNCH(ctx, (k1s_loglikes_packed<5, 4>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      else if (pack == 2) KHG_LAUNCH(ctx, (k1s_loglikes_packed<5, 2>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      else if (KS == 5) KHG_LAUNCH(ctx, (k1s_loglikes<5>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
+      else KHG_LAUNCH(ctx, (k1s_loglikes<10>), dim3(u->n_schunks), dim3(512), lds, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
     rc = m->wimgs_sync.after_read(ctx->stream);
@@ -756,9 +751,9 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reac
   const bool aligned = (m->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(u->feats_d) & 15) == 0);
   if (u->n_chunks > 0) {
     KernelTimer kt(ctx, "k1_loglikes");
-    if (m->KQ == 10 && k1_nf(ctx, 10) == 6) launch_k1<10, 6, 2>(a, u->n_chunks, aligned, ctx->stream);
-    else if (m->KQ == 10) launch_k1<10, 5, 2>(a, u->n_chunks, aligned, ctx->stream);
-    else launch_k1<20, 5, 1>(a, u->n_chunks, aligned, ctx->stream);
+    if (m->KQ == 10 && k1_nf(ctx, 10) == 6) launch_k1<10, 6, 2>(ctx, a, u->n_chunks, aligned, ctx->stream);
+    else if (m->KQ == 10) launch_k1<10, 5, 2>(ctx, a, u->n_chunks, aligned, ctx->stream);
+    else launch_k1<20, 5, 1>(ctx, a, u->n_chunks, aligned, ctx->stream);
     HIPCHK(hipGetLastError());
   }
   u->ll_valid = true;
@@ -848,10 +843,10 @@ int k1_band_repair(khg_ctx* ctx, khg_utts* u, int32_t* status_d, int repair_bit,
     const unsigned gr = (unsigned)std::min<int64_t>(256, ((int64_t)u->n_schunks + 511) / 512);
     if (u->band_ks == 5) {
       HIPCHK(hipFuncSetAttribute((const void*)k1s_repair<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-      hipLaunchKernelGGL((k1s_repair<5>), dim3(gr), dim3(512), lds_r, side, ra, (int)u->n_schunks);
+      KHG_LAUNCH(ctx, (k1s_repair<5>), dim3(gr), dim3(512), lds_r, side, ra, (int)u->n_schunks);
     } else {
       HIPCHK(hipFuncSetAttribute((const void*)k1s_repair<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-      hipLaunchKernelGGL((k1s_repair<10>), dim3(gr), dim3(512), lds_r, side, ra, (int)u->n_schunks);
+      KHG_LAUNCH(ctx, (k1s_repair<10>), dim3(gr), dim3(512), lds_r, side, ra, (int)u->n_schunks);
     }
   }
   HIPCHK(hipGetLastError());

@@ -141,7 +141,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   }
   if (gmem) {
     KernelTimer kt(ctx, "k2_viterbi_dp");
-    hipLaunchKernelGGL((k2_viterbi_dp<1, 1, false, true>), dim3(u->n_utt), dim3(nthr), 0, ctx->stream, a);
+    KHG_LAUNCH(ctx, (k2_viterbi_dp<1, 1, false, true>), dim3(u->n_utt), dim3(nthr), 0, ctx->stream, a);
   } else {
     // in-degree <= 2 (a linear transcript's chain of HMM states: self-loop + forward arc): the two-slot instantiation, a sixth fewer
     // instructions per layer than the three-slot one (the layer loop is bound by VALU issue; every slot is evaluated, empty or not)
@@ -167,7 +167,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     else if (KSsel == 4) X((k2_viterbi_dp<4, 3, true>));                                                       \
     else X((k2_viterbi_dp<1, 1, false>));
 #define K2_SET_LDS(FN) HIPCHK(hipFuncSetAttribute((const void*)FN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp))
-#define K2_LAUNCH(FN) hipLaunchKernelGGL(FN, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a)
+#define K2_LAUNCH(FN) KHG_LAUNCH(ctx, FN, dim3(u->n_utt), dim3(nthr), lds_dp, ctx->stream, a)
     if (lds_dp > 48 * 1024) { K2_DP_CASES(K2_SET_LDS) }
     KernelTimer kt(ctx, "k2_viterbi_dp");
     K2_DP_CASES(K2_LAUNCH)
@@ -195,16 +195,16 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     KernelTimer kt(ctx, "k2_viterbi_faithful", side);
     if (wave_gm) {
       if (lds_w_mut > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w_mut));
-      hipLaunchKernelGGL(k2_viterbi_faithful_wave<true>, dim3(u->n_utt), dim3(64), lds_w_mut, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
+      KHG_LAUNCH(ctx, k2_viterbi_faithful_wave<true>, dim3(u->n_utt), dim3(64), lds_w_mut, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
     } else if (wave_lds) {
       const size_t lds_w = lds_w_mut + lds_w_graph;
       if (lds_w > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
-      hipLaunchKernelGGL(k2_viterbi_faithful_wave<false>, dim3(u->n_utt), dim3(64), lds_w, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
+      KHG_LAUNCH(ctx, k2_viterbi_faithful_wave<false>, dim3(u->n_utt), dim3(64), lds_w, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
     } else if (lane_gm) {
-      hipLaunchKernelGGL(k2_viterbi_faithful<true>, dim3(u->n_utt), dim3(64), 0, side, a);
+      KHG_LAUNCH(ctx, k2_viterbi_faithful<true>, dim3(u->n_utt), dim3(64), 0, side, a);
     } else {
       if (lds_f > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-      hipLaunchKernelGGL(k2_viterbi_faithful<false>, dim3(u->n_utt), dim3(64), lds_f, side, a);
+      KHG_LAUNCH(ctx, k2_viterbi_faithful<false>, dim3(u->n_utt), dim3(64), lds_f, side, a);
     }
   }
   HIPCHK(hipGetLastError());

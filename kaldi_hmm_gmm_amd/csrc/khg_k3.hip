@@ -57,22 +57,8 @@ static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use)
   int rc = k1_maxima(ctx, m, u, &xk);          // the set's column maxima (cached) and the model's (wmax, gcmax; cached per version)
   if (rc) return rc;
   if (m->k3_xb.empty()) {
-    uint32_t* b_d = nullptr;
-    rc = dev_alloc(&b_d, 64);
-    if (rc) return rc;
-    std::vector<uint32_t> hb(64, 0);
-    hipError_t e = hipMemsetAsync(b_d, 0, 64 * sizeof(uint32_t), ctx->stream);
-    if (e == hipSuccess) {
-      const int64_t n = m->sumG;
-      hipLaunchKernelGGL(k3_model_xbound, dim3((int)std::min<int64_t>(2048, (n * D + 255) / 256)), dim3(256), 0, ctx->stream, m->miv_d, m->iv_d, n, D, b_d);
-      e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), b_d, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    DEVFREE(b_d);
-    if (e != hipSuccess) return khg_set_error(KHG_E_HIP, hipGetErrorString(e));
-    m->k3_xb.assign((size_t)D, 0.0f);
-    for (int d = 0; d < D; ++d) memcpy(&m->k3_xb[(size_t)d], &hb[(size_t)d], sizeof(float));
+    if (m->wmax.empty() || (int)m->k3_xb_raw.size() != D) { m->wmax.clear(); rc = model_stats(ctx, m); if (rc) return rc; }
+    m->k3_xb = m->k3_xb_raw;          // (read with the column maxima: k0_model_stats, one pass per parameter version)
     m->k3_ex.assign((size_t)K, 0);
     bool ok = true;
     for (int d = 0; d < D; ++d) {
@@ -152,9 +138,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       KernelTimer kt(ctx, "k3_bucket");
       // KHG_OPT_K3_BUCKET = 1: cursor-bump scatter (bucket order depends on the atomics)
       if (ctx->opt[KHG_OPT_K3_BUCKET] == 1 || u->N >= (int64_t)INT_MAX) {
-        hipLaunchKernelGGL(k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
-        hipLaunchKernelGGL(k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
+        KHG_LAUNCH(ctx, k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
+        KHG_LAUNCH(ctx, k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
+        KHG_LAUNCH(ctx, k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
       } else if (ctx->opt[KHG_OPT_K3_BUCKET] == 2 && m->P <= K3_CS_MAXP) {
         // the library's own stable counting sort (khg_k3_accstats.hip.inc: k3_cs_*; opt-in: 1.27 ms against the radix sort's 0.80 at the
         // bench size): blocks of CB consecutive frames
@@ -174,11 +160,11 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
           HIPCHK(hipFuncSetAttribute((const void*)k3_cs_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
         }
         if (lds_p > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k3_cs_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-        if (ldst) hipLaunchKernelGGL(k3_cs_hist<true>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
-        else hipLaunchKernelGGL(k3_cs_hist<false>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
-        hipLaunchKernelGGL(k3_cs_scan, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, c);
-        hipLaunchKernelGGL(k3_cs_starts, dim3(1), dim3(1024), 0, ctx->stream, a, c);
-        hipLaunchKernelGGL(k3_cs_place, dim3(nblk), dim3(64 * nw), lds_p, ctx->stream, a, c);
+        if (ldst) KHG_LAUNCH(ctx, k3_cs_hist<true>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
+        else KHG_LAUNCH(ctx, k3_cs_hist<false>, dim3(nblk), dim3(256), lds_h, ctx->stream, a, c);
+        KHG_LAUNCH(ctx, k3_cs_scan, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, c);
+        KHG_LAUNCH(ctx, k3_cs_starts, dim3(1), dim3(1024), 0, ctx->stream, a, c);
+        KHG_LAUNCH(ctx, k3_cs_place, dim3(nblk), dim3(64 * nw), lds_p, ctx->stream, a, c);
       } else {
         // stable sort of (pdf, frame) pairs: frames of a pdf stay in frame order; the bucket boundaries are read
         // off the sorted keys
@@ -198,11 +184,11 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
           { int rt = u_alloc(u, reinterpret_cast<char**>(&u->sort_tmp_d), need); if (rt) return rt; }
           u->sort_tmp_bytes = need;
         }
-        if (tm->num_tids <= K3_LDS_TIDS) hipLaunchKernelGGL(k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
-        else hipLaunchKernelGGL(k3_sort_keys<false>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        if (tm->num_tids <= K3_LDS_TIDS) KHG_LAUNCH(ctx, k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        else KHG_LAUNCH(ctx, k3_sort_keys<false>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
                                                   reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
-        hipLaunchKernelGGL(k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
+        KHG_LAUNCH(ctx, k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
       }
     }
     // Work items of the accumulate kernels (k3_make_items): ny_base slices per pdf, more for a pdf whose bucket is far above the
@@ -234,7 +220,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         if (rc2) return rc2;
         u->k3_part_n = (size_t)max_slots * nsum1;
       }
-      hipLaunchKernelGGL(k3_make_items, dim3(1), dim3(1024), 0, ctx->stream, a, ny_base, target, (int)max_items, (int)std::min<int64_t>(max_slots, INT_MAX),
+      KHG_LAUNCH(ctx, k3_make_items, dim3(1), dim3(1024), 0, ctx->stream, a, ny_base, target, (int)max_items, (int)std::min<int64_t>(max_slots, INT_MAX),
                          reinterpret_cast<K3Item*>(u->k3_items_d), u->k3_item_off_d);
       a.items = reinterpret_cast<const K3Item*>(u->k3_items_d); a.item_off = u->k3_item_off_d;
       return KHG_OK;
@@ -302,11 +288,11 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
     if (f16b) {                                                                                                          \
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave16<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
-      hipLaunchKernelGGL((k3_accumulate_wave16<NBV>), dim3(nblk), dim3(256), lds16, ctx->stream, a);                     \
-    } else if (exact_b && f16a) hipLaunchKernelGGL((k3_accumulate_wave<NBV, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);    \
-    else if (exact_b) hipLaunchKernelGGL((k3_accumulate_wave<NBV>), dim3(nblk), dim3(256), lds, ctx->stream, a);         \
-    else hipLaunchKernelGGL((k3_accumulate_wave32<NBV>), dim3(nblk), dim3(256), lds32, ctx->stream, a);                  \
-    hipLaunchKernelGGL((k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a);                                 \
+      KHG_LAUNCH(ctx, (k3_accumulate_wave16<NBV>), dim3(nblk), dim3(256), lds16, ctx->stream, a);                     \
+    } else if (exact_b && f16a) KHG_LAUNCH(ctx, (k3_accumulate_wave<NBV, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);    \
+    else if (exact_b) KHG_LAUNCH(ctx, (k3_accumulate_wave<NBV>), dim3(nblk), dim3(256), lds, ctx->stream, a);         \
+    else KHG_LAUNCH(ctx, (k3_accumulate_wave32<NBV>), dim3(nblk), dim3(256), lds32, ctx->stream, a);                  \
+    KHG_LAUNCH(ctx, (k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a);                                 \
   } while (0)
       switch (nb) {
         case 1: K3_WAVE_LAUNCH(1); break;
@@ -319,7 +305,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }
       a.pdf0 = 0; a.npdf = m->P;
-      hipLaunchKernelGGL(k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
+      KHG_LAUNCH(ctx, k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
     } else if (use_mfma) {
       // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
       const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions
@@ -335,12 +321,12 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, "k3_accumulate");
-          if (m->KQ == 10 && maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10 && maxG <= 128) hipLaunchKernelGGL((k3_accumulate_mfma<10, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10 && maxG <= 192) hipLaunchKernelGGL((k3_accumulate_mfma<10, 3>), dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 10) hipLaunchKernelGGL((k3_accumulate_mfma<10, 4>), dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else if (maxG <= 64) hipLaunchKernelGGL((k3_accumulate_mfma<20, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else hipLaunchKernelGGL((k3_accumulate_mfma<20, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          if (m->KQ == 10 && maxG <= 64) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 128) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10 && maxG <= 192) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 3>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 10) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 4>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (maxG <= 64) KHG_LAUNCH(ctx, (k3_accumulate_mfma<20, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else KHG_LAUNCH(ctx, (k3_accumulate_mfma<20, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
         }
         if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }
@@ -359,9 +345,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, "k3_accumulate");
-          if (m->KQ == 10) hipLaunchKernelGGL(k3_accumulate<10>, dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else if (m->KQ == 20) hipLaunchKernelGGL(k3_accumulate<20>, dim3(nblk), dim3(256), lds, ctx->stream, a);
-          else hipLaunchKernelGGL(k3_accumulate<0>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          if (m->KQ == 10) KHG_LAUNCH(ctx, k3_accumulate<10>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else if (m->KQ == 20) KHG_LAUNCH(ctx, k3_accumulate<20>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+          else KHG_LAUNCH(ctx, k3_accumulate<0>, dim3(nblk), dim3(256), lds, ctx->stream, a);
         }
         if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
       }

@@ -73,7 +73,7 @@ static int mle_update_rows(khg_ctx* ctx, khg_model* m, const khg_accs* acc, cons
   a.remove_low = o->remove_low_count_gaussians; a.flags = flags; a.pdf0 = p0;
   if (np > 0) {
     KernelTimer kt(ctx, "k4_mle_update");
-    hipLaunchKernelGGL(k4_mle_update, dim3(np), dim3(256), lds, ctx->stream, a);
+    KHG_LAUNCH(ctx, k4_mle_update, dim3(np), dim3(256), lds, ctx->stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && floor_d) e = hipStreamSynchronize(ctx->stream);
@@ -114,7 +114,7 @@ static int mle_update_finish(khg_ctx* ctx, khg_model* m, float* objf_change, flo
     if (!rc) rc = dev_alloc(&iv2, (size_t)out * D);
     if (!rc) {
       KernelTimer kt(ctx, "k4_compact");
-      hipLaunchKernelGGL(k4_compact, dim3(P), dim3(256), 0, ctx->stream, m->gauss_off_d, new_off_d, D, m->weights_d, m->gconsts_d,
+      KHG_LAUNCH(ctx, k4_compact, dim3(P), dim3(256), 0, ctx->stream, m->gauss_off_d, new_off_d, D, m->weights_d, m->gconsts_d,
                          m->miv_d, m->iv_d, w2, gc2, miv2, iv2);
     }
     if (!rc) {
@@ -280,7 +280,7 @@ extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* target
     hipError_t e = hipMemsetAsync(bad_d, 0, sizeof(int32_t), ctx->stream);
     if (e == hipSuccess) {
       KernelTimer kt(ctx, "k4_split");
-      hipLaunchKernelGGL(k4_split, dim3(P), dim3(256), 0, ctx->stream, m->gauss_off_d, new_off_d, D, m->weights_d, m->miv_d, m->iv_d, w2, gc2,
+      KHG_LAUNCH(ctx, k4_split, dim3(P), dim3(256), 0, ctx->stream, m->gauss_off_d, new_off_d, D, m->weights_d, m->miv_d, m->iv_d, w2, gc2,
                          miv2, iv2, rand_d, rand_off_d, perturb, bad_d);
       e = hipGetLastError();
     }
@@ -343,7 +343,7 @@ extern "C" int khg_model_merge(khg_ctx* ctx, khg_model* m, const int32_t* target
     hipError_t e = hipMemsetAsync(bad_d, 0, sizeof(int32_t), ctx->stream);
     if (e == hipSuccess) {
       KernelTimer kt(ctx, "k4_merge");
-      hipLaunchKernelGGL(k4_merge, dim3(P), dim3(256), 0, ctx->stream, a);
+      KHG_LAUNCH(ctx, k4_merge, dim3(P), dim3(256), 0, ctx->stream, a);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, bad_d, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
@@ -413,7 +413,7 @@ extern "C" int khg_model_scale_weights(khg_ctx* ctx, khg_model* m, int32_t n, co
   if (!rc) {
     hipError_t e = hipMemsetAsync(bad_d, 0, sizeof(int32_t), ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k4_scale_weights, dim3(n), dim3(64), 0, ctx->stream, pdfs_d, m->gauss_off_d, m->D, scale, m->weights_d,
+      KHG_LAUNCH(ctx, k4_scale_weights, dim3(n), dim3(64), 0, ctx->stream, pdfs_d, m->gauss_off_d, m->D, scale, m->weights_d,
                          m->gconsts_d, m->miv_d, m->iv_d, bad_d);
       e = hipGetLastError();
     }

@@ -163,6 +163,7 @@ struct KModel {
   py::dict mle_rows_download(int first_pdf, int n_pdf);
   void mle_rows_upload(py::dict d);
   py::dict mle_update_finish();
+  void invalidate() { Check(khg_model_invalidate(h)); }
   void scale_weights(Arr<int32_t> pdfs, float scale) { Check(khg_model_scale_weights(ctx->h, h, (int32_t)pdfs.shape(0), pdfs.data(), scale)); }
   void split(Arr<int32_t> targets, float perturb, py::object randn) {
     if (targets.shape(0) != num_pdfs) throw py::value_error("split: one target per pdf");
@@ -564,6 +565,7 @@ PYBIND11_MODULE(_kaldi_hmm_gmm_amd, m) {
       .def("mle_rows_download", &KModel::mle_rows_download).def("mle_rows_upload", &KModel::mle_rows_upload)
       .def("mle_update_finish", &KModel::mle_update_finish)
       .def("scale_weights", &KModel::scale_weights)
+      .def("invalidate", &KModel::invalidate)
       .def("split", &KModel::split, py::arg("targets"), py::arg("perturb_factor"), py::arg("randn"))
       .def("merge", &KModel::merge, py::arg("targets"))
       .def("download", &KModel::download, py::arg("weights") = true)

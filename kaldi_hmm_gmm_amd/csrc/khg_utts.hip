@@ -253,7 +253,7 @@ extern "C" int khg_utts_features_changed(khg_utts* u) {
 
 extern "C" int khg_utts_destroy(khg_utts* u) {
   if (!u) return KHG_OK;
-  if (u->small && u->ctx) {
+  if (u->small && u->ctx && khg_ctx_alive(u->ctx)) {      // (a handle may be destroyed after its context: nothing is in flight then)
     // arena scratch is reused by the next set at once (hipFree would have waited for the device): nothing of this set may be in flight
     khg_ctx* c = u->ctx;
     for (int i = 0; i < khg_ctx::NSIDE; ++i)
