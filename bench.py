@@ -853,6 +853,13 @@ def main():
                                "apart) the correct path wins by a wide margin, so few utterances leave the certified path -- "
                                "tools/fallback_stress.py is the flat-start-like case (~45 % through the fallback)"}
 
+    if recipe_line is not None or fp32_line is not None:
+        step()                                        # the block holds the headline configuration's sums (over all shards) again
+        torch.cuda.synchronize()
+        del ar_events[args.steps:]
+        for c in ctxs:
+            c.timings()
+
     # what every rank did, so that imbalance between the shards is visible on the one line rank 0 prints
     mine_info = {"rank": rank, "utterances": n_local, "frames": frames_local, "seconds": dt_local,
                  "kernel_ms_per_step": {k: v / args.steps for k, v in sorted(kernel_ms.items())}}
