@@ -256,75 +256,97 @@ __global__ void k0_nhalf(const float* __restrict__ iv, int64_t n, float* __restr
 //   maxima[1536]            max |gconst|
 //   ubound[first tile of p] log sum_g exp(gconst_g + 0.5 sum_d mi^2 / iv) + margin: the BAND form's fill (k1s_ubound's rule, fp64,
 //                           every sum in a fixed order: the value does not depend on the launch)
-// k0_model_stats: one THREAD per Gaussian row -- it walks its row's D dimensions from a lane-dependent start (so the 64 rows of a wave
-// hit 64 different addresses of the workgroup's maxima in LDS), sums the row's fp64 terms in that fixed order and leaves
-// c_g = gconst_g + 0.5 sum_d mi^2 / iv in a scratch array; k0_model_ubound: one wave per pdf, log-sum-exp of its c_g in fp64 in a
-// fixed order.  Both deterministic for a given model layout.
+// One workgroup walks pdfs p = block, block + grid, ...; a thread owns one dimension of one of the 256 / D rows of a pass (two
+// dimensions when D > 256); a row's fp64 terms are summed by its first thread, a pdf's components by wave 0.
 struct K0StatsArgs {
   const float *gconsts, *miv, *iv;
-  const int32_t *gauss_off, *pdf_tile_off;     // pdf_tile_off / ubound NULL: no tile image (D > 80)
+  const int32_t *gauss_off, *pdf_tile_off;     // pdf_tile_off / ubound may be NULL (no tile image: D > 80)
   int P, D;
-  int64_t sumG;
   uint32_t* maxima;                            // [1537], zeroed by the caller
-  double* c;                                   // [sumG]
   float* ubound;
 };
-__global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
-  __shared__ unsigned s_max[3][512];
-  const int D = a.D, t = threadIdx.x;
-  for (int i = t; i < 3 * 512; i += 256) (&s_max[0][0])[i] = 0u;
-  __syncthreads();
-  float m_gc = 0.0f;
-  auto bits = [](float v) { return __float_as_uint((fabsf(v) <= 3.0e38f) ? fabsf(v) : INFINITY); };      // k1h_absmax's rule (NaN / inf -> +inf)
-  for (int64_t g = (int64_t)blockIdx.x * 256 + t; g < a.sumG; g += (int64_t)gridDim.x * 256) {
-    const float* mr = a.miv + g * D;
-    const float* vr = a.iv + g * D;
-    double term = 0.0;
-    int d = (int)((unsigned)t % (unsigned)D);
-    for (int k = 0; k < D; ++k) {
-      const float mi = mr[d], v = vr[d];
-      if (mi != -INFINITY) atomicMax(&s_max[0][d], bits(mi));
-      if (v != -INFINITY) atomicMax(&s_max[1][d], bits(v));
-      float b = fabsf(mi / v) + 8.0f * rsqrtf(v);                  // k3_model_xbound's rule
-      if (!(b < 3.0e38f)) b = INFINITY;
-      atomicMax(&s_max[2][d], __float_as_uint(b));
-      term += 0.5 * (double)mi * (double)mi / (double)v;
-      d = d + 1 == D ? 0 : d + 1;
-    }
-    const float gc = a.gconsts[g];
-    if (gc != -INFINITY) m_gc = fmaxf(m_gc, __uint_as_float(bits(gc)));
-    if (a.c) a.c[g] = term + (double)gc;
-  }
-  __syncthreads();
-  for (int d = t; d < D; d += 256) {
-    if (s_max[0][d]) atomicMax(a.maxima + d, s_max[0][d]);
-    if (s_max[1][d]) atomicMax(a.maxima + 512 + d, s_max[1][d]);
-    if (s_max[2][d]) atomicMax(a.maxima + 1024 + d, s_max[2][d]);
-  }
-  if (m_gc > 0.0f) atomicMax(a.maxima + 1536, __float_as_uint(m_gc));
+__device__ __forceinline__ float k0_absmax_step(float m, float v) {
+  if (v == -INFINITY) return m;
+  return (fabsf(v) <= 3.0e38f) ? fmaxf(m, fabsf(v)) : INFINITY;
 }
-__global__ __launch_bounds__(64) void k0_model_ubound(K0StatsArgs a) {
-  const int p = blockIdx.x, lane = threadIdx.x;
-  const int g0 = a.gauss_off[p], g1 = a.gauss_off[p + 1];
-  double m = -INFINITY, ssum = 0.0;
-  for (int g = g0 + lane; g < g1; g += 64) {
-    const double c = a.c[g];
-    if (c > m) { ssum = ssum * exp(m - c) + 1.0; m = c; }
-    else if (c > -INFINITY) ssum += exp(c - m);
+__global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
+  constexpr int NPASS = 8;                   // passes of 256 / D rows whose terms are parked before one barrier and one round of row sums
+  __shared__ double s_term[NPASS][256];
+  __shared__ double s_c[1024];
+  const int D = a.D, Dc = D < 256 ? D : 256, RP = 256 / Dc, t = threadIdx.x;
+  const int r = t / Dc, d0 = t - r * Dc;
+  const bool act = r < RP;
+  float m_miv[2] = {0.0f, 0.0f}, m_iv[2] = {0.0f, 0.0f}, m_xb[2] = {0.0f, 0.0f}, m_gc = 0.0f;
+  for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+    const int g0 = a.gauss_off[p], g1 = a.gauss_off[p + 1];
+    double lm = -INFINITY, ls = 0.0;             // wave 0's per-lane running (max, sum) over this pdf's components
+    for (int gb = g0; gb < g1; gb += 1024) {     // <= 1024 components at a time through s_c
+      const int ge = min(g1, gb + 1024);
+      for (int g = gb; g < ge; g += RP * NPASS) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          double term = 0.0;
+          const int row = g + ps * RP + r;
+          if (act && row < ge) {
+            int j = 0;
+            for (int d = d0; d < D; d += Dc, ++j) {
+              const float mi = a.miv[(size_t)row * D + d], v = a.iv[(size_t)row * D + d];
+              m_miv[j] = k0_absmax_step(m_miv[j], mi);
+              m_iv[j] = k0_absmax_step(m_iv[j], v);
+              float b = fabsf(mi / v) + 8.0f * rsqrtf(v);
+              if (!(b < 3.0e38f)) b = INFINITY;
+              m_xb[j] = fmaxf(m_xb[j], b);
+              term += 0.5 * (double)mi * (double)mi / (double)v;
+            }
+            if (d0 == 0) m_gc = k0_absmax_step(m_gc, a.gconsts[row]);
+          }
+          s_term[ps][t] = term;
+        }
+        __syncthreads();
+        for (int idx = t; idx < NPASS * RP; idx += 256) {      // one thread per parked row: pass idx / RP, row slot idx % RP, its Dc terms in order
+          const int ps = idx / RP, rr = idx - ps * RP, row = g + ps * RP + rr;
+          if (row < ge) {
+            double c = 0.0;
+            for (int k2 = 0; k2 < Dc; ++k2) c += s_term[ps][rr * Dc + k2];
+            s_c[row - gb] = c + (double)a.gconsts[row];
+          }
+        }
+        __syncthreads();
+      }
+      if (t < 64) {
+        for (int i = t; i < ge - gb; i += 64) {
+          const double c = s_c[i];
+          if (c > lm) { ls = ls * exp(lm - c) + 1.0; lm = c; }
+          else if (c > -INFINITY) ls += exp(c - lm);
+        }
+      }
+      __syncthreads();
+    }
+    if (t < 64 && a.ubound && a.pdf_tile_off) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_xor(lm, o), s2 = __shfl_xor(ls, o);
+        const double mm = fmax(lm, m2);
+        if (mm > -INFINITY) ls = ls * exp(lm - mm) + s2 * exp(m2 - mm);
+        lm = mm;
+      }
+      if (t == 0 && a.pdf_tile_off[p + 1] > a.pdf_tile_off[p]) {
+        double v = lm + log(ls);
+        if (!(v == v) || v == -INFINITY) v = 0.0;         // an all-dead pdf scores -inf everywhere (an error in K1 either way): any finite fill
+        if (v > 3.0e38) v = 3.0e38;
+        float vf = (float)v;
+        if ((double)vf < v) vf = nextafterf(vf, INFINITY);        // rounded up: still a bound
+        a.ubound[a.pdf_tile_off[p]] = vf + 1.0e-3f + 1.0e-5f * fabsf(vf);
+      }
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const double m2 = __shfl_xor(m, o), s2 = __shfl_xor(ssum, o);
-    const double mm = fmax(m, m2);
-    if (mm > -INFINITY) ssum = ssum * exp(m - mm) + s2 * exp(m2 - mm);
-    m = mm;
-  }
-  if (lane == 0 && a.pdf_tile_off[p + 1] > a.pdf_tile_off[p]) {
-    double v = m + log(ssum);
-    if (!(v == v) || v == -INFINITY) v = 0.0;         // an all-dead pdf scores -inf everywhere (an error in K1 either way): any finite fill
-    if (v > 3.0e38) v = 3.0e38;
-    float vf = (float)v;
-    if ((double)vf < v) vf = nextafterf(vf, INFINITY);        // rounded up: still a bound
-    a.ubound[a.pdf_tile_off[p]] = vf + 1.0e-3f + 1.0e-5f * fabsf(vf);
+  if (act) {
+    int j = 0;
+    for (int d = d0; d < D; d += Dc, ++j) {
+      if (m_miv[j] > 0.0f) atomicMax(a.maxima + d, __float_as_uint(m_miv[j]));
+      if (m_iv[j] > 0.0f) atomicMax(a.maxima + 512 + d, __float_as_uint(m_iv[j]));
+      if (m_xb[j] > 0.0f) atomicMax(a.maxima + 1024 + d, __float_as_uint(m_xb[j]));
+    }
+    if (d0 == 0 && m_gc > 0.0f) atomicMax(a.maxima + 1536, __float_as_uint(m_gc));
   }
 }
 
@@ -340,20 +362,11 @@ int model_stats(khg_ctx* ctx, khg_model* m) {
     if (rc) return rc;
     m->ubound_tiles = m->ntiles;
   }
-  const bool ub = m->KQ != 0;
-  if (ub && m->stats_c_n < m->sumG) {
-    DEVFREE(m->stats_c_d);
-    int rc = dev_alloc(&m->stats_c_d, (size_t)m->sumG);
-    if (rc) return rc;
-    m->stats_c_n = m->sumG;
-  }
   HIPCHK(hipMemsetAsync(m->stats_d, 0, 1537 * sizeof(uint32_t), ctx->stream));
-  K0StatsArgs a{m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, ub ? m->pdf_tile_off_d : nullptr, m->P, D, m->sumG, m->stats_d, ub ? m->stats_c_d : nullptr,
-                ub ? m->ubound_d : nullptr};
+  K0StatsArgs a{m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->KQ != 0 ? m->pdf_tile_off_d : nullptr, m->P, D, m->stats_d, m->KQ != 0 ? m->ubound_d : nullptr};
   {
     KernelTimer kt(ctx, "k0_model_stats");
-    KHG_LAUNCH(ctx, k0_model_stats, dim3((unsigned)std::min<int64_t>(2048, (m->sumG + 255) / 256)), dim3(256), 0, ctx->stream, a);
-    if (ub) KHG_LAUNCH(ctx, k0_model_ubound, dim3((unsigned)m->P), dim3(64), 0, ctx->stream, a);
+    KHG_LAUNCH(ctx, k0_model_stats, dim3((unsigned)std::min(m->P, 2048)), dim3(256), 0, ctx->stream, a);
   }
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> h(1537);
@@ -482,7 +495,7 @@ extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   { std::lock_guard<std::mutex> lk(g_model_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
   m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->stats_d); DEVFREE(m->stats_c_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->stats_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;

@@ -185,7 +185,6 @@ struct khg_model {
   std::vector<float> k3_xb;        // per dim: max over the Gaussians of |mean| + 8 sigma (empty: not computed)
   std::vector<float> k3_xb_raw;    // the same as model_stats read it (valid with wmax); k3_xb / k3_ex / k3_S are derived from it in khg_k3.hip
   uint32_t* stats_d = nullptr;     // landing block of k0_model_stats
-  double* stats_c_d = nullptr; int64_t stats_c_n = 0;   // its per-Gaussian fp64 scratch (c_g of the band's upper bounds)
   std::vector<int32_t> k3_ex;      // [80] per k = 2 d + kind
   int32_t k3_S = 0;
   bool k3_f16_ok = false;          // the model side of the form's domain holds
