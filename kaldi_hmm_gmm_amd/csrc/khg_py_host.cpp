@@ -112,6 +112,7 @@ void BindGmm(py::module_& m) {
       .def_property_readonly("num_gauss", &DiagGmm::NumGauss)
       .def_property_readonly("dim", &DiagGmm::Dim)
       .def_property_readonly("valid_gconsts", &DiagGmm::ValidGconsts)
+      .def_property_readonly("_version", &DiagGmm::version)      // mutation counter (what AmDiagGmm keys its cached device model by)
       .def_property_readonly("gconsts", [](DiagGmm& g) { return Vec1(g.gconsts()); })
       .def_property("weights", [](DiagGmm& g) { return Vec1(g.weights()); }, [](DiagGmm& g, Arr<float> w) { g.SetWeights(w.data(), (size_t)w.size()); })
       .def_property_readonly("means_invvars", [](DiagGmm& g) { return Vec2(g.means_invvars(), g.NumGauss(), g.Dim()); })
@@ -233,6 +234,7 @@ void BindGmm(py::module_& m) {
       .def(py::init<>())
       .def_property_readonly("dim", &AmDiagGmm::Dim)
       .def_property_readonly("num_pdfs", &AmDiagGmm::NumPdfs)
+      .def_property_readonly("_version", &AmDiagGmm::Version)
       .def_property_readonly("num_gauss", &AmDiagGmm::NumGauss)
       .def("num_gauss_in_pdf", [](AmDiagGmm& a, int i) { return a.GetPdf(i)->NumGauss(); }, py::arg("pdf_index"))
       .def("init", &AmDiagGmm::Init, py::arg("proto"), py::arg("num_pdfs"))

@@ -176,3 +176,48 @@ def test_align_after_the_band_model_changed_or_died_is_an_error(khg, ctx):
     with pytest.raises(k.KhgError, match="destroyed or updated"):
         us.align(tm, beam=200.0, acoustic_scale=0.1)
     us.close(); tm.close()
+
+
+@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 13, False), (45, 20, 39, True), (60, 70, 40, True), (24, 40, 80, False), (21, 130, 23, True)])
+def test_per_utterance_calls_across_model_shapes(khg, ctx, P, G, D, ragged):
+    """Every K1 / K3 form the shapes select (packed small pdfs, the wave forms, the block form at D = 80, the VALU form above 128
+    Gaussians) through the per-utterance API with arena scratch, against the batched path; plus what the reference's wrapper does with
+    an utterance it cannot align and with an empty one."""
+    m = synth.make_model(P, G, D, seed=100 + P, ragged=ragged)
+    n = 10
+    ut = synth.make_utts(m, n, seed=P, min_phones=2, max_phones=6)
+    am, tm = synth.host_objects(m)
+    cfg = khg.AlignConfig(beam=200.0, retry_beam=0.0, careful=False)
+    accs = khg.AccumAmDiagGmm(); accs.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    tacc, alis = None, []
+    for u in range(n):
+        feats = np.ascontiguousarray(ut.feats[ut.frame_off[u]: ut.frame_off[u + 1]])
+        ans = khg.gmm_align_compiled(am_gmm=am, transition_model=tm, utt=str(u), fst=synth.utt_fst(ut.graphs, u), feats=feats, align_config=cfg,
+                                     acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+        assert ans["num_done"] == 1
+        alis.append(np.asarray(ans["alignment"], np.int32))
+        _, tacc = khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=feats, ali=ans["alignment"], transition_accs=tacc)
+    cost = np.zeros(m.num_tids + 1, np.float32)
+    c = np.asarray(tm.scaled_trans_cost(1.0, 0.1), np.float32); cost[: c.shape[0]] = c
+    res, st = _batched(khg, ctx, m, am, ut, n, cost, 200.0, 0.0)
+    np.testing.assert_array_equal(np.concatenate(alis), res["ali"])
+    occ = np.concatenate([np.asarray(accs.get_acc(p).occupancy) for p in range(P)])
+    mean = np.concatenate([np.asarray(accs.get_acc(p).mean_accumulator) for p in range(P)])
+    var = np.concatenate([np.asarray(accs.get_acc(p).variance_accumulator) for p in range(P)])
+    np.testing.assert_allclose(occ, st["occ"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(mean, st["mean_acc"], rtol=2e-5, atol=2e-6 * np.abs(st["mean_acc"]).max())
+    np.testing.assert_allclose(var, st["var_acc"], rtol=2e-5, atol=2e-6 * np.abs(st["var_acc"]).max())
+    # an utterance too short for its graph: num_error, empty alignment, counters as decoder-wrappers.cc:35-107 leaves them
+    u = int(np.argmax(np.diff(ut.graphs["state_off"])))
+    short = np.ascontiguousarray(ut.feats[ut.frame_off[u]: ut.frame_off[u] + 2])
+    ans = khg.gmm_align_compiled(am_gmm=am, transition_model=tm, utt="short", fst=synth.utt_fst(ut.graphs, u), feats=short, align_config=cfg,
+                                 acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1, num_done=3, num_error=1, tot_like=-5.0, frame_count=7)
+    assert (ans["num_done"], ans["num_error"], ans["tot_like"], ans["frame_count"], ans["alignment"], ans["words"]) == (3, 2, -5.0, 7, [], [])
+    # no frames at all: nothing accumulated, log_like 0
+    before = accs.tot_count
+    ll, tacc2 = khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=np.zeros((0, D), np.float32), ali=[], transition_accs=tacc.copy())
+    assert ll == 0.0 and accs.tot_count == before and np.array_equal(tacc2, tacc)
+    with pytest.raises(khg.KhgError):
+        khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=short, ali=[1], transition_accs=None)       # len(ali) != frames
+    with pytest.raises(khg.KhgError):
+        khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=short, ali=[0, 10 ** 6], transition_accs=None)

@@ -687,3 +687,59 @@ def test_map_update_vs_oracle_and_reference_option_tests():
     with pytest.raises(khg.KhgError, match="Flags in argument do not match"):
         a = khg.AccumDiagGmm(am.get_pdf(0), khg.GmmUpdateFlags.kGmmWeights)
         khg.map_diag_gmm_update(cfg, a, khg.GmmUpdateFlags.kGmmAll & 7, khg.DiagGmm(gmm=am.get_pdf(0)))
+
+
+def test_mutation_versions_follow_every_way_of_changing_a_model():
+    """AmDiagGmm caches its device model by a mutation version (khg_host_gmm.hpp): every mutator of a DiagGmm -- reached directly or
+    through the reference-returning get_pdf(i) -- and every change of the list of pdfs must move it; readers must not."""
+    import pickle
+
+    rng = np.random.default_rng(3)
+    g = khg.DiagGmm(nmix=3, dim=4)
+    g.set_weights(np.full(3, 1 / 3, np.float32)); g.set_means(rng.standard_normal((3, 4)).astype(np.float32)); g.set_invvars(np.ones((3, 4), np.float32))
+    g.compute_gconsts()
+    am = khg.AmDiagGmm()
+    am.init(g, 4)
+    seen = [am._version]
+
+    def moved(what):
+        v = am._version
+        assert v > seen[-1], what
+        seen.append(v)
+
+    def same(what):
+        assert am._version == seen[-1], what
+
+    _ = am.get_pdf(1).weights, am.get_pdf(1).means, am.num_gauss, am.flat(), pickle.dumps(am), am.get_gaussian_mean(0, 1), am._pdfs
+    same("readers")
+    am.get_pdf(2).set_weights(np.asarray([0.5, 0.25, 0.25], np.float32)); moved("set_weights through get_pdf")
+    am.get_pdf(2).compute_gconsts(); moved("compute_gconsts")
+    am.get_pdf(0).set_component_mean(1, np.zeros(4, np.float32)); moved("set_component_mean")
+    am.get_pdf(0).set_component_inv_var(1, np.full(4, 2.0, np.float32)); moved("set_component_inv_var")
+    am.get_pdf(0).set_component_weight(0, 0.4); moved("set_component_weight")
+    am.get_pdf(0).set_invvars_and_means(np.ones((3, 4), np.float32), np.zeros((3, 4), np.float32)); moved("set_invvars_and_means")
+    am.get_pdf(0).compute_gconsts(); moved("compute_gconsts again")
+    am.set_gaussian_mean(1, 0, np.ones(4, np.float32)); moved("set_gaussian_mean")
+    am.get_pdf(1).compute_gconsts(); moved("gconsts")
+    am.get_pdf(3).perturb(0.01, randn=lambda shape: np.zeros(shape, np.float32)); moved("perturb")
+    am.get_pdf(3).split(4, 0.01, randn=lambda n: np.zeros(n, np.float32)); moved("split")
+    am.get_pdf(3).merge(2); moved("merge")
+    am.get_pdf(3).remove_component(0, True); moved("remove_component")
+    am.get_pdf(3).compute_gconsts(); moved("gconsts")
+    am.get_pdf(1).interpolate(0.5, am.get_pdf(0)); moved("interpolate")
+    am.get_pdf(1).copy_from_diag_gmm(am.get_pdf(0)); moved("copy_from_diag_gmm")
+    am.get_pdf(1).resize(2, 4); moved("resize")
+    am.get_pdf(1).copy_from_diag_gmm(am.get_pdf(0)); moved("copy back")
+    am.add_pdf(g); moved("add_pdf")
+    am.split_by_count(np.full(5, 100.0, np.float32), 20, 0.01, 0.2, 1.0, randn=lambda n: np.zeros(n, np.float32)); moved("split_by_count")
+    am.merge_by_count(np.full(5, 100.0, np.float32), 8, 0.2, 1.0); moved("merge_by_count")
+    go, gc, w, miv, iv = am.flat()
+    am.set_flat(go, w, gc, miv, iv); moved("set_flat")
+    other = khg.AmDiagGmm(); other.copy_from_am_diag_gmm(am)
+    same("being copied from")
+    am.copy_from_am_diag_gmm(other); moved("copy_from_am_diag_gmm")
+    am._pdfs = other._pdfs; moved("replacing the list of pdfs")
+    # a pdf shared with another model: a mutation through either is seen by both
+    v_other = other._version
+    am.get_pdf(0).set_weights(am.get_pdf(0).weights); moved("shared pdf")
+    assert other._version > v_other
