@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 passes for profiles/ (round 4): kernel trace + stats, then PMC passes in their own runs (the pool refuses --pmc
+# rocprofv3 passes for profiles/ (round 5): kernel trace + stats, then PMC passes in their own runs (the pool refuses --pmc
 # combined with other trace domains).  The bench runs its default workload (f16x2s K1) with the fp32-MFMA side line.
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_r4
+OUT=gpurun_out/prof_r5
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --per-call-utts 0 --no-recipe-beam-line"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log
