@@ -26,7 +26,7 @@ void* arena_alloc(khg_ctx* ctx, size_t bytes) {
       a.cap = SIZE_MAX;
       return nullptr;
     }
-    a.dev = static_cast<char*>(d); a.host = static_cast<char*>(h); a.cap = KHG_ARENA_BYTES; a.top = a.base = 0;
+    a.dev = static_cast<char*>(d); a.host = static_cast<char*>(h); a.cap = KHG_ARENA_BYTES; a.top = a.base = 256;      // (no allocation shares the block's own address: a handle destroyed after its context must not hipFree it)
   }
   bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
   if (a.top + bytes > a.cap) return nullptr;
