@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
   constexpr int NPASS = 8;                   // passes of 256 / D rows whose terms are parked before one barrier and one round of row sums
   __shared__ double s_term[NPASS][256];
   __shared__ double s_c[1024];
+  __shared__ unsigned s_bmax;                // max over the pdf's components of |gconst| + 0.5 sum mi^2 / iv (float bits): the magnitude K1's rounding scales with
   const int D = a.D, Dc = D < 256 ? D : 256, RP = 256 / Dc, t = threadIdx.x;
   const int r = t / Dc, d0 = t - r * Dc;
   const bool act = r < RP;
@@ -280,6 +281,8 @@ __global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
   for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
     const int g0 = a.gauss_off[p], g1 = a.gauss_off[p + 1];
     double lm = -INFINITY, ls = 0.0;             // wave 0's per-lane running (max, sum) over this pdf's components
+    if (t == 0) s_bmax = 0u;
+    __syncthreads();
     for (int gb = g0; gb < g1; gb += 1024) {     // <= 1024 components at a time through s_c
       const int ge = min(g1, gb + 1024);
       for (int g = gb; g < ge; g += RP * NPASS) {
@@ -309,6 +312,8 @@ __global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
             double c = 0.0;
             for (int k2 = 0; k2 < Dc; ++k2) c += s_term[ps][rr * Dc + k2];
             s_c[row - gb] = c + (double)a.gconsts[row];
+            const float bs = (float)(c + fabs((double)a.gconsts[row]));
+            if (bs > 0.0f && bs < 3.0e38f) atomicMax(&s_bmax, __float_as_uint(bs));
           }
         }
         __syncthreads();
@@ -335,7 +340,9 @@ __global__ __launch_bounds__(256) void k0_model_stats(K0StatsArgs a) {
         if (v > 3.0e38) v = 3.0e38;
         float vf = (float)v;
         if ((double)vf < v) vf = nextafterf(vf, INFINITY);        // rounded up: still a bound
-        a.ubound[a.pdf_tile_off[p]] = vf + 1.0e-3f + 1.0e-5f * fabsf(vf);
+        // + what K1's own rounding can add to a value near the bound: its error scales with the magnitude of the cancelling terms
+        // (tests hold K1 to 1e-5 + 1e-6 B; 2^-20 B here), which for un-normalised features dwarfs the fixed margin
+        a.ubound[a.pdf_tile_off[p]] = vf + 1.0e-3f + 1.0e-5f * fabsf(vf) + ldexpf(__uint_as_float(s_bmax), -20);
       }
     }
   }

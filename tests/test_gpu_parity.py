@@ -1025,3 +1025,45 @@ def test_acc_stats_fp16_phase_b_vs_oracle_and_fp64_form(ctx, opt, G, weight):
         np.testing.assert_allclose(b["occ"], oa.occ, rtol=2e-5, atol=1e-6 * abs(weight))
         np.testing.assert_allclose(b["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.mean_acc).max())
         np.testing.assert_allclose(b["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
+
+
+def test_band_fill_bounds_k1_values_for_unnormalised_features(ctx, opt):
+    """The band form fills dead cells with log sum_g exp(gconst_g + 0.5 sum_d mi^2 / iv) + a margin.  With un-normalised features
+    (means of ~100 standard deviations: gconst and the quadratic terms are ~1e5 each and cancel) an fp32 evaluation of that sum, or
+    a margin that ignores the magnitude of the cancelling terms, falls BELOW values K1 itself computes near a component's mean
+    (round-4 advisor finding): the bound is summed in fp64 and its margin scales with the terms (k0_model_stats)."""
+    from kaldi_hmm_gmm_amd import synth
+    opt.k1("f16x2s")
+    m = synth.make_model(90, 40, 40, seed=11)
+    m.means[:] = (m.means * np.float32(30.0) + np.float32(100.0)).astype(np.float32)
+    m.means_invvars[:] = (m.means * m.inv_vars).astype(np.float32)
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    ut = synth.make_utts(m, 10, seed=4, min_phones=10, max_phones=30)
+    cost = np.zeros(m.num_tids + 1, np.float32)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.loglikes(dm)
+    full = us.download_loglikes()
+    us.loglikes(dm, band=True)
+    part = us.download_loglikes()
+    poff, pdfs = us.pdf_lists()
+    last_dev = us.pdf_last_frames()
+    checked = 0
+    for u in range(us.n_utt):
+        T = int(ut.frame_off[u + 1] - ut.frame_off[u])
+        for j in range(int(poff[u + 1] - poff[u])):
+            lp = int(last_dev[poff[u] + j])
+            t1 = min(32 * (max(lp, 0) // 32 + 1), full[u].shape[1])
+            tail = part[u][j, t1:T]
+            differs = tail != full[u][j, t1:T]
+            if differs.any():                                  # a filled tile: one value, no smaller than anything K1 computes for this pdf
+                fill = tail[differs][0]
+                assert (tail[differs] == fill).all()
+                assert fill >= full[u][j, :T].max(), (u, j, float(fill), float(full[u][j, :T].max()))
+                checked += 1
+    assert checked > 50
+    # and the frames a pdf's own component emitted score close to that bound: the margin is not vacuous headroom
+    res_b = us.align(tm, beam=200.0, acoustic_scale=0.1)
+    us.loglikes(dm)
+    res_f = us.align(tm, beam=200.0, acoustic_scale=0.1)
+    np.testing.assert_array_equal(res_b["ali"], res_f["ali"])
+    us.close(); tm.close(); dm.close()
