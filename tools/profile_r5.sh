@@ -5,6 +5,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r5
 rm -rf $OUT; mkdir -p $OUT
+python3 -c "import bench; print(bench.csrc_sha())" > $OUT/csrc_sha.txt      # identity of the sources these passes run on
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --per-call-utts 0 --no-recipe-beam-line"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log

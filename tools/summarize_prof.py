@@ -95,7 +95,11 @@ for _fn in sorted(os.listdir(_d)):            # same identity bench.py computes 
         with open(os.path.join(_d, _fn), "rb") as _fh:
             _h.update(_fn.encode() + b"\0" + _fh.read())
 durs = trace_durations()
-summary = {"command": f"tools/profile_{TAG}.sh", "csrc_sha": _h.hexdigest()[:16], "kernels": {}}
+_sha = _h.hexdigest()[:16]
+_sha_file = os.path.join(SRC, "csrc_sha.txt")      # written on the GPU box by the profile script: the sources that were PROFILED
+if os.path.exists(_sha_file):
+    _sha = open(_sha_file).read().strip() or _sha
+summary = {"command": f"tools/profile_{TAG}.sh", "csrc_sha": _sha, "kernels": {}}
 if bench_line:
     nb = bench_line["roofline"]["launches_per_step"]
     summary["utterances_per_launch"] = bench_line["config"]["utterances"] / nb
