@@ -557,17 +557,30 @@ def main():
         fsub = feats[int(fo[0]): int(fo[-1])]
         sets.append(UtteranceSet(ctxs[b % len(ctxs)], tm, fo - fo[0], (fsub.data_ptr(), feats), dim=D, graphs=sub))
     accs = DeviceAccs(ctxs[0], dm, tm)
-    acc_t = accs.as_torch() if (dist_on and args.allreduce == "torch") else None
     comm = None
+    inproc_fallback = None
     if dist_on and args.allreduce in ("khg", "khg-f32"):
+        comm_err = None
         try:
+            if os.environ.get("KHG_BENCH_FAIL_COMM") == "2":
+                raise RuntimeError("KHG_BENCH_FAIL_COMM=2: pretending ncclCommInitRank failed")
             # (a one-rank group -- KHG_BENCH_FORCE_DIST=1 -- forms a real one-rank RCCL communicator: the same entry points run)
             comm = make_comm(ctxs[0], one_rank=True, timeout_s=float(os.environ.get("KHG_BENCH_COMM_TIMEOUT", "180")))
-        except BaseException as ex:               # a rank without its communicator must not leave the others in a barrier
-            print(f"bench.py: rank {rank}/{world} (device {local}): the library's RCCL communicator could not be formed: {ex!r}",
+        except BaseException as ex:
+            comm_err = repr(ex)
+            print(f"bench.py: rank {rank}/{world} (device {local}): the library's RCCL communicator could not be formed: {comm_err}",
                   file=sys.stderr, flush=True)
-            os._exit(3)                           # fresh-process semantics only: exit (never re-exec a process that touched the GPU);
-            #                                       the launcher (torch.distributed.run) then takes the other ranks down
+        # Under the driver's own torch.distributed.run there is no launch ladder: a rank that cannot form the LIBRARY's communicator must
+        # not cost the run.  The ranks agree (over the process group, which is up) whether all of them have it; if not, every rank drops
+        # to torch.distributed's all-reduce on a view of the same block -- another code path in the same process, nothing re-executed.
+        okt = torch.tensor([0.0 if comm_err else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if float(okt[0]) < 0.5:
+            inproc_fallback = {"tried": "--allreduce %s (library RCCL communicator)" % args.allreduce, "error": comm_err or "another rank failed",
+                               "now": "--allreduce torch"}
+            comm = None                      # (a communicator only some ranks hold is left alone: closing it is itself a collective)
+            args.allreduce = "torch"
+    acc_t = accs.as_torch() if (dist_on and args.allreduce == "torch") else None
     host_block = np.zeros(accs.size, np.float64) if args.allreduce == "host" else None
 
     T = np.diff(ut.frame_off)
@@ -1035,6 +1048,7 @@ def main():
             "check": {"acc_total_frames": res["total_frames"], "frames_in_set": frames_global, "avg_loglike_per_frame":
                       res["total_log_like"] / max(res["total_frames"], 1.0)},
             "allreduce": args.allreduce if dist_on else None,
+            "allreduce_fallback_in_process": inproc_fallback,
             "rccl": rccl_info,
             "scaling_efficiency_vs_n1_shard": None if alone_ms is None else {
                 "value": alone_ms / (dt / args.steps * 1e3), "shards_without_exchange_ms_per_step": alone_ms, "ms_per_step": dt / args.steps * 1e3,

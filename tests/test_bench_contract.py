@@ -102,3 +102,15 @@ def test_dist_selftest_is_quick_and_checks_the_sum():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["selftest"] == "ok" and d["sum"] == d["want"] == 1.0 and d["bytes"] > 1000000 and d["allreduce"] == "khg"
+
+
+@pytest.mark.gpu
+def test_in_process_fallback_when_the_library_communicator_cannot_be_formed():
+    """Under the driver's own torch.distributed.run there is no launch ladder: if the library's RCCL communicator cannot be formed
+    (KHG_BENCH_FAIL_COMM=2) the ranks agree over the process group and every rank drops to torch.distributed's all-reduce on the
+    same block -- the line still comes out, with what happened recorded in it."""
+    d = _run({"KHG_BENCH_FORCE_DIST": "1", "KHG_BENCH_FAIL_COMM": "2"}, "--no-cpu-baseline", "--per-call-utts", "0", "--no-recipe-beam-line", "--no-fp32-line")
+    assert d["allreduce"] == "torch" and d["rccl"] is None and d["value"] > 1e6
+    fb = d["allreduce_fallback_in_process"]
+    assert fb["now"] == "--allreduce torch" and "KHG_BENCH_FAIL_COMM=2" in fb["error"]
+    assert d["check"]["acc_total_frames"] == d["config"]["frames_per_step"] and d["allreduce_ms_per_step"] is not None
