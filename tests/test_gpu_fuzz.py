@@ -1,6 +1,6 @@
 """The randomised sweeps and the larger end-to-end check ON THE RECORD (they only existed as manual scripts):
 seeded, time-boxed slices of tests/fuzzlib.py under `pytest -m gpu`, and the end-to-end mismatch report written to
-profiles/r4_parity_report.json (also gpurun_out/, which is what comes back from the GPU box)."""
+profiles/r5_parity_report.json (also gpurun_out/, which is what comes back from the GPU box)."""
 import json
 import os
 import sys
@@ -50,7 +50,7 @@ def test_end_to_end_against_oracle_with_mismatch_report(ctx):
     rep["runs"] += [dict(r, scoring_model=hard["scoring_model"]) for r in hard["runs"]]
     for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
-            with open(os.path.join(d, "r4_parity_report.json"), "w") as fh:
+            with open(os.path.join(d, "r5_parity_report.json"), "w") as fh:
                 json.dump(rep, fh, indent=1)
     assert rep["frames"] > 60000
     for run in rep["runs"]:
