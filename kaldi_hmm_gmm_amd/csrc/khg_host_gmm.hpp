@@ -153,6 +153,10 @@ class DiagGmm {
 // ---- csrc/am-diag-gmm.h:96 ---------------------------------------------------------------------------------------------
 class AmDiagGmm {
  public:
+  AmDiagGmm() = default;
+  // a copy shares the DiagGmm objects (as the vector of shared pointers always did) but never the cached device handle
+  AmDiagGmm(const AmDiagGmm& o) : pdfs_(o.pdfs_) {}
+  AmDiagGmm& operator=(const AmDiagGmm& o) { if (this != &o) { pdfs_ = o.pdfs_; struct_version_ = NextVersion(); } return *this; }
   int Dim() const { return pdfs_.empty() ? 0 : pdfs_[0]->Dim(); }
   int NumPdfs() const { return (int)pdfs_.size(); }
   int NumGauss() const { int n = 0; for (auto& p : pdfs_) n += p->NumGauss(); return n; }
