@@ -1,0 +1,16 @@
+#!/bin/bash
+# Long randomised sweeps on the final sources (tests/fuzzlib.py), 1500 s each -> gpurun_out/r5_fuzz_*_1500.txt
+cd "$GRAFT_REPO_ROOT"
+for what in parity graphs; do
+python - > gpurun_out/r5_fuzz_${what}_1500.txt 2>&1 <<PY
+import sys
+sys.path.insert(0, "tests")
+import fuzzlib
+from kaldi_hmm_gmm_amd import Context
+ctx = Context(0)
+f = fuzzlib.fuzz_parity if "$what" == "parity" else fuzzlib.fuzz_graphs
+print("$what fuzz ok:", f(ctx, budget=1500.0, seed=9511 if "$what" == "parity" else 9512))
+PY
+tail -n 1 gpurun_out/r5_fuzz_${what}_1500.txt
+done
+python tools/fallback_stress.py > gpurun_out/r5_fallback_stress.txt 2>&1; tail -n 5 gpurun_out/r5_fallback_stress.txt
