@@ -102,7 +102,7 @@ def self_launch(args):
     if asked == "khg":
         rungs += [("--allreduce torch", ["--allreduce", "torch"]), ("--allreduce khg --c1-parts 1", ["--allreduce", "khg", "--c1-parts", "1"])]
     tried = []
-    t_self = float(os.environ.get("KHG_BENCH_SELFTEST_TIMEOUT", "300"))
+    t_self = float(os.environ.get("KHG_BENCH_SELFTEST_TIMEOUT", "900"))      # (the first `import torch` on a fresh box alone can take minutes)
     t_run = float(os.environ.get("KHG_BENCH_RUN_TIMEOUT", "3000"))
     for k, (name, extra) in enumerate(rungs):
         if not args.dist_selftest:
