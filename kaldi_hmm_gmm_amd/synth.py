@@ -16,6 +16,8 @@ CONFIGS = {
     "tri2000x32": (2000, 32, 40),
     "tri5000x64": (5000, 64, 40),
     "stress10000x128": (10000, 128, 80),
+    # probe shapes (not BASELINE configs): config #5's pdfs with a model small enough for the Infinity Cache
+    "probe1000x128": (1000, 128, 80),
 }
 
 
