@@ -105,6 +105,9 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_DEBUG 14         /* 1: planning statistics to stderr                                              [KHG_DEBUG] */
 #define KHG_OPT_K3_PHASE_A 15    /* per-Gaussian log-likelihoods of K3's wave form: 0 on the fp16 matrix cores in K1's f16x2s arithmetic where the model-derived scales hold, 1 the fp32 MFMA chain [KHG_K3_PHASEA=f32] */
 #define KHG_OPT_COUNT 16
+/* Read-only figures (khg_ctx_get_option only): the per-call scratch block behind small utterance sets (DESIGN.md "per-utterance calls"). */
+#define KHG_INFO_SCRATCH_BYTES 100   /* bytes of the block in use (its top), 0 before the first small set */
+#define KHG_INFO_SCRATCH_BLOCKS 101  /* live allocations inside it */
 int khg_ctx_set_option(khg_ctx *ctx, int option, int value);
 int khg_ctx_get_option(const khg_ctx *ctx, int option, int *value);
 

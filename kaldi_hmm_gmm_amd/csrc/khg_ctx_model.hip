@@ -31,8 +31,8 @@ void* arena_alloc(khg_ctx* ctx, size_t bytes) {
   bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
   if (a.top + bytes > a.cap) return nullptr;
   void* p = a.dev + a.top;
+  a.blocks.emplace_back(a.top, a.top + bytes);
   a.top += bytes;
-  ++a.live;
   return p;
 }
 void arena_mark_dirty(khg_ctx* ctx, const void* dev_ptr, size_t bytes) {
@@ -60,7 +60,15 @@ bool khg_arena_release(void* p) {
   for (khg_ctx* c : g_ctxs) {
     KhgArena& a = c->arena;
     if (!a.owns(p)) continue;
-    if (--a.live <= 0) { a.live = 0; a.top = a.base; a.dirty.clear(); }   // the owners waited for their streams before releasing
+    // (the owner waited for its streams before releasing.)  Blocks are a stack: the top falls back to the end of the last live one
+    const size_t off = (size_t)((char*)p - a.dev);
+    for (size_t i = a.blocks.size(); i-- > 0;)
+      if (a.blocks[i].first == off) { a.blocks.erase(a.blocks.begin() + (long)i); break; }
+    a.top = a.blocks.empty() ? a.base : a.blocks.back().second;
+    for (size_t i = a.dirty.size(); i-- > 0;) {                                      // staged bytes of dead allocations
+      if (a.dirty[i].first >= a.top) a.dirty.erase(a.dirty.begin() + (long)i);
+      else if (a.dirty[i].second > a.top) a.dirty[i].second = a.top;
+    }
     return true;
   }
   return false;
@@ -149,6 +157,10 @@ extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   return KHG_OK;
 }
 extern "C" int khg_ctx_get_option(const khg_ctx* c, int opt, int* value) {
+  if (c && value && (opt == KHG_INFO_SCRATCH_BYTES || opt == KHG_INFO_SCRATCH_BLOCKS)) {
+    *value = opt == KHG_INFO_SCRATCH_BYTES ? (c->arena.dev ? (int)c->arena.top : 0) : (int)c->arena.blocks.size();
+    return KHG_OK;
+  }
   if (!c || !value || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_get_option: bad arguments");
   *value = c->opt[opt];
   return KHG_OK;

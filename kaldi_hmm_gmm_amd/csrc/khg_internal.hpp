@@ -41,7 +41,8 @@ struct khg_timing { std::string name; hipEvent_t e0, e1; };
 struct KhgArena {
   char *dev = nullptr, *host = nullptr;
   size_t cap = 0, top = 0, base = 0;          // base: bytes reserved for the context itself (the error word)
-  int live = 0;
+  std::vector<std::pair<size_t, size_t>> blocks;  // live allocations [offset, end), ascending: a release pops the dead tail, so per-call
+                                                  // sets made beside a longer-lived small set reuse the same bytes instead of filling the block
   std::vector<std::pair<size_t, size_t>> dirty;   // staged mirror ranges not yet copied to the device (neighbours merged)
   bool owns(const void* p) const { return dev && (const char*)p >= dev && (const char*)p < dev + cap; }
   char* mirror(const void* dev_ptr) const { return host + ((const char*)dev_ptr - dev); }

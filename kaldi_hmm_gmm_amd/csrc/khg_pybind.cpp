@@ -78,6 +78,8 @@ struct KContext {
                                                "k2_prof", "k3_bucket", "k3_form", "k3_phase_b", "k3_ny", "debug", "k3_phase_a"};
     const std::string n = o.cast<std::string>();
     for (int i = 0; i < KHG_OPT_COUNT; ++i) if (n == names[i]) return i;
+    if (n == "scratch_bytes") return KHG_INFO_SCRATCH_BYTES;       // read-only
+    if (n == "scratch_blocks") return KHG_INFO_SCRATCH_BLOCKS;
     throw py::key_error(n);
   }
   int get_option(py::object name) { int v = 0; Check(khg_ctx_get_option(h, opt_id(name), &v)); return v; }

@@ -221,3 +221,40 @@ def test_per_utterance_calls_across_model_shapes(khg, ctx, P, G, D, ragged):
         khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=short, ali=[1], transition_accs=None)       # len(ali) != frames
     with pytest.raises(khg.KhgError):
         khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=short, ali=[0, 10 ** 6], transition_accs=None)
+
+
+def test_scratch_block_is_reused_beside_a_longer_lived_small_set(khg, ctx):
+    """The per-call scratch block (DESIGN.md "per-utterance calls") is a stack: a small set that stays alive -- a held-out utterance
+    kept resident, say -- must not make every later per-call set add to it until the block is full (the calls would silently fall
+    back to hipMalloc).  Results of the resident set stay right while its neighbours' bytes are reused."""
+    P, G, D = 30, 8, 13
+    m = synth.make_model(P, G, D, seed=5)
+    ut = synth.make_utts(m, 6, seed=3, min_phones=3, max_phones=8)
+    go, gc, _, miv, iv = synth.host_objects(m)[0].flat()
+    dm = khg.DeviceModel(ctx, go, gc, miv, iv)
+    tm = khg.DeviceTransitions(ctx, m.id2pdf)
+
+    def one(u):
+        f0, f1 = int(ut.frame_off[u]), int(ut.frame_off[u + 1])
+        return khg.UtteranceSet(ctx, None, np.array([0, f1 - f0], np.int64), np.ascontiguousarray(ut.feats[f0:f1]))
+
+    assert ctx.get_option("scratch_blocks") == 0
+    keep = one(0)
+    keep.loglikes(dm)
+    ref = np.array(keep.download_loglikes(), copy=True)
+    base_bytes, base_blocks = ctx.get_option("scratch_bytes"), ctx.get_option("scratch_blocks")
+    assert base_blocks > 0 and base_bytes > 256
+    peak = 0
+    for it in range(300):
+        us = one(1 + it % 5)
+        us.loglikes(dm)
+        got = us.download_loglikes()
+        assert np.isfinite(np.asarray(got)).all()
+        peak = max(peak, ctx.get_option("scratch_bytes"))
+        us.close()
+        assert ctx.get_option("scratch_bytes") == base_bytes and ctx.get_option("scratch_blocks") == base_blocks, it
+    assert peak < base_bytes + (4 << 20), "one per-call set's worth above the resident one, not 300"
+    np.testing.assert_array_equal(np.asarray(keep.download_loglikes()), ref)
+    keep.close()
+    assert ctx.get_option("scratch_blocks") == 0 and ctx.get_option("scratch_bytes") == 256
+    tm.close(); dm.close()
