@@ -126,11 +126,18 @@ double AccumAmDiagGmm::AccumulateAli(const AmDiagGmm& model, const TransitionMod
   const int64_t N = frame_off[n_utt];
   if (N == 0) return 0.0;
   KHG_REQUIRE(NumAccs() == model.NumPdfs(), "gmm_accs.NumAccs() == am_gmm.NumPdfs() assertion failed");
-  const int D = model.Dim(), nt = tm.NumTransitionIds();
+  const int nt = tm.NumTransitionIds();
   for (int64_t t = 0; t < N; ++t) KHG_REQUIRE(ali[t] >= 1 && ali[t] <= nt, "gmm_acc_stats_ali: transition-id out of range");
+  return AccumulateOnDevice(model, tm.DeviceTm(DefaultCtx()), nt, feats, frame_off, n_utt, ali, weight);
+}
+
+// One K3 call into the device-resident block (made for this model version and this many transition-ids); -> the call's own
+// sum of weight * log-like.  `dt` == nullptr: the per-frame entry points' table, transition-id = pdf + 1, owned by the block.
+double AccumAmDiagGmm::AccumulateOnDevice(const AmDiagGmm& model, khg_tm* dt, int nt, const float* feats, const int64_t* frame_off, int n_utt,
+                                          const int32_t* ali, float weight) {
+  const int D = model.Dim();
   khg_ctx* ctx = DefaultCtx();
   khg_model* dm = model.DeviceModel(ctx);
-  khg_tm* dt = tm.DeviceTm(ctx);
   const uint64_t mv = model.Version();
   if (dev_ && (dev_->ctx != ctx || dev_->model_version != mv || dev_->num_tids != nt)) {
     // another model (or the same one after an update that may have moved its layout): what is pending belongs to the old layout
@@ -146,9 +153,16 @@ double AccumAmDiagGmm::AccumulateAli(const AmDiagGmm& model, const TransitionMod
       KHG_REQUIRE(accs_[(size_t)p]->NumGauss() == G && accs_[(size_t)p]->Dim() == D, "gmm_accs was not initialised for this model (AccumAmDiagGmm.init)");
       d->gauss_off[(size_t)p + 1] = d->gauss_off[(size_t)p] + G;
     }
-    CApi(khg_accs_create(ctx, dm, dt, &d->h));
+    if (!dt) {
+      std::vector<int32_t> id2pdf((size_t)nt + 1, 0);
+      for (int p = 0; p < nt; ++p) id2pdf[(size_t)p + 1] = p;
+      CApi(khg_tm_create(ctx, nt, id2pdf.data(), &d->pdf_tm));
+    }
+    CApi(khg_accs_create(ctx, dm, dt ? dt : d->pdf_tm, &d->h));
     dev_ = d;
   }
+  if (!dt) dt = dev_->pdf_tm;
+  KHG_REQUIRE(dt != nullptr, "AccumAmDiagGmm: the device block was made for a transition model, not for per-frame calls");
   UttsH us;
   CApi(khg_utts_create(ctx, nullptr, n_utt, D, frame_off, feats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &us.h));
   CApi(khg_ali_upload(ctx, us.h, ali));
@@ -159,6 +173,22 @@ double AccumAmDiagGmm::AccumulateAli(const AmDiagGmm& model, const TransitionMod
   const double ll = sc[1] - dev_->seen_ll;
   dev_->seen_frames = sc[0]; dev_->seen_ll = sc[1];
   return ll;
+}
+
+// csrc/mle-am-diag-gmm.cc:41-52 (AccumulateForGmm): one frame for one pdf -- the loop body of the reference's own
+// scripts/gmm_acc_stats_ali.py:46-56.  The same device-resident block as AccumulateAli (a set of one frame, transition-id = pdf + 1):
+// no model upload, no statistics download per frame; the return value is the frame's log-likelihood.
+float AccumAmDiagGmm::AccumulateForGmm(const AmDiagGmm& model, const float* data, size_t n, int i, float weight) {
+  Chk(i);
+  KHG_REQUIRE(NumAccs() == model.NumPdfs(), "gmm_accs.NumAccs() == am_gmm.NumPdfs() assertion failed");
+  KHG_REQUIRE((int)n == model.Dim(), "data.size() == Dim() assertion failed");
+  if (weight == 0.0f) return model.GetPdf(i)->LogLikelihood(data, n);      // nothing to add; the reference still returns the likelihood
+  const int64_t fo[2] = {0, 1};
+  const int32_t tid = i + 1;
+  const int nt = model.NumPdfs();
+  if (dev_ && !dev_->pdf_tm && dev_->num_tids == nt) { Flush(); dev_.reset(); }   // a block AccumulateAli made for a transition model with exactly as many ids has no pdf table
+  const double wll = AccumulateOnDevice(model, nullptr, nt, data, fo, 1, &tid, weight);
+  return (float)(wll / (double)weight);
 }
 
 }  // namespace khg

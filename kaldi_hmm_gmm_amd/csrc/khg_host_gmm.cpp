@@ -822,13 +822,6 @@ float AccumAmDiagGmm::TotStatsCount() const {
   for (auto& a : accs_) s += NpSum(a->occupancy().data(), a->occupancy().size());
   return (float)s;
 }
-float AccumAmDiagGmm::AccumulateForGmm(const AmDiagGmm& model, const float* data, size_t n, int i, float weight) {
-  Chk(i);
-  const float ll = accs_[(size_t)i]->AccumulateFromDiag(*model.GetPdf(i), data, n, weight);
-  total_log_like_ += (double)(ll * weight);
-  total_frames_ += (double)weight;
-  return ll;
-}
 float AccumAmDiagGmm::AccumulateForGmmTwoFeats(const AmDiagGmm& model, const float* d1, size_t n1, const float* d2, size_t n2, int i, float weight) {
   Chk(i);
   std::vector<float> post;

@@ -303,6 +303,8 @@ class AccumAmDiagGmm {
   // the host accumulators (Flush: one download per EM pass).  -> the log-likelihood of these frames (tot_like_this_file).
   double AccumulateAli(const AmDiagGmm& model, const TransitionModel& tm, const float* feats, const int64_t* frame_off, int n_utt, const int32_t* ali,
                        float weight = 1.0f);
+  double AccumulateOnDevice(const AmDiagGmm& model, khg_tm* dt, int num_tids, const float* feats, const int64_t* frame_off, int n_utt, const int32_t* ali,
+                            float weight);                     // khg_host_align.cpp: the one K3 call behind AccumulateAli and AccumulateForGmm
   bool HasDeviceStats() const { return dev_ && dev_->pending; }
   void Flush() const;        // pending device sums -> host accumulators (then the device block is zero again)
 
@@ -315,7 +317,8 @@ class AccumAmDiagGmm {
     std::vector<int32_t> gauss_off;
     double seen_frames = 0.0, seen_ll = 0.0;                   // the block's running totals at the last call (a call's own log-like = the difference)
     bool pending = false;
-    ~Dev() { if (h) khg_accs_destroy(h); }
+    khg_tm* pdf_tm = nullptr;                                  // the per-frame entry points' table (transition-id = pdf + 1), when the block was made by them
+    ~Dev() { if (h) khg_accs_destroy(h); if (pdf_tm) khg_tm_destroy(pdf_tm); }
   };
   mutable std::vector<std::shared_ptr<AccumDiagGmm>> accs_;
   mutable double total_frames_ = 0.0, total_log_like_ = 0.0;

@@ -258,3 +258,58 @@ def test_scratch_block_is_reused_beside_a_longer_lived_small_set(khg, ctx):
     keep.close()
     assert ctx.get_option("scratch_blocks") == 0 and ctx.get_option("scratch_bytes") == 256
     tm.close(); dm.close()
+
+
+def test_per_frame_accumulate_is_the_same_device_block(khg, ctx):
+    """The loop body of the reference's own scripts/gmm_acc_stats_ali.py:46-56 -- accumulate_for_gmm(model, data=feats[i],
+    gmm_index=pdf, weight=1.0) once per frame -- against one _acc_stats_ali call per utterance: same statistics, same log-likes,
+    no model upload per frame (the device block stays pending until something reads it), and the two ways mix."""
+    P, G, D, n = 300, 16, 40, 3
+    m = synth.make_model(P, G, D, seed=21)
+    ut = synth.make_utts(m, n, seed=4, min_phones=3, max_phones=6)
+    am, tm = synth.host_objects(m)
+
+    def aligned(u):
+        f0, f1 = int(ut.frame_off[u]), int(ut.frame_off[u + 1])
+        feats = np.ascontiguousarray(ut.feats[f0:f1])
+        r = khg.gmm_align_compiled(am_gmm=am, transition_model=tm, utt=str(u), fst=synth.utt_fst(ut.graphs, u), feats=feats,
+                                   align_config=khg.AlignConfig(beam=200.0, retry_beam=0.0, careful=False), acoustic_scale=0.1,
+                                   transition_scale=1.0, self_loop_scale=0.1)
+        return feats, np.asarray(r["alignment"], np.int32)
+
+    a = khg.AccumAmDiagGmm(); a.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    b = khg.AccumAmDiagGmm(); b.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    tot_a = tot_b = 0.0
+    for u in range(n):
+        feats, ali = aligned(u)
+        ll_b, _ = khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=b, transition_model=tm, feats=feats, ali=ali.tolist(), transition_accs=None)
+        tot_b += ll_b
+        per_frame = []
+        for t in range(feats.shape[0]):
+            pdf = tm.transition_id_to_pdf(int(ali[t]))
+            per_frame.append(a.accumulate_for_gmm(model=am, data=feats[t], gmm_index=pdf, weight=1.0))
+        assert a._has_device_stats, "per-frame calls leave their sums on the device"
+        tot_a += float(np.sum(per_frame))
+        # each return value is that frame's log-likelihood under its pdf
+        want = [am.get_pdf(tm.transition_id_to_pdf(int(ali[t]))).log_likelihood(data=feats[t]) for t in range(0, feats.shape[0], 17)]
+        np.testing.assert_allclose(per_frame[::17], want, rtol=2e-5, atol=2e-4)
+        if u == 1:       # and the per-utterance entry point into the same accumulator (another transition-id table: the block is re-made)
+            khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=a, transition_model=tm, feats=feats, ali=ali.tolist(), transition_accs=None)
+            khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=b, transition_model=tm, feats=feats, ali=ali.tolist(), transition_accs=None)
+    assert tot_a == pytest.approx(tot_b, rel=2e-6)
+    assert a.tot_count == pytest.approx(b.tot_count, rel=1e-12) and a.tot_log_like == pytest.approx(b.tot_log_like, rel=2e-6)
+    assert not a._has_device_stats
+    for p in range(0, P, 7):
+        x, y = a.get_acc(p), b.get_acc(p)
+        np.testing.assert_allclose(x.occupancy, y.occupancy, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(x.mean_accumulator, y.mean_accumulator, rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(x.variance_accumulator, y.variance_accumulator, rtol=2e-5, atol=1e-3)
+    # weight 0 adds nothing and still returns the likelihood; a fractional weight scales the sums
+    c = khg.AccumAmDiagGmm(); c.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    feats, ali = aligned(0)
+    ll0 = c.accumulate_for_gmm(model=am, data=feats[0], gmm_index=5, weight=0.0)
+    assert ll0 == pytest.approx(am.get_pdf(5).log_likelihood(data=feats[0]), abs=2e-4) and c.tot_count == 0.0
+    llh = c.accumulate_for_gmm(model=am, data=feats[0], gmm_index=5, weight=0.5)
+    assert llh == pytest.approx(ll0, abs=2e-4)
+    assert c.tot_count == pytest.approx(0.5) and c.tot_log_like == pytest.approx(0.5 * llh, rel=1e-5)
+    assert float(np.sum(c.get_acc(5).occupancy)) == pytest.approx(0.5, rel=1e-5)

@@ -46,6 +46,19 @@ def main():
     t1 = time.perf_counter()
     print(f"{cfg}: {n - k} utts after warm-up: align {1e3 * sa / (n - k):.3f} ms/utt, acc {1e3 * sb / (n - k):.3f} ms/utt, "
           f"{fr / (sa + sb):.0f} frames/s; tot_count {tot} (first host read {1e3 * (t1 - t0):.1f} ms)")
+    # the reference's own loop body (scripts/gmm_acc_stats_ali.py:46-56): one accumulate_for_gmm per FRAME -- launch-bound by construction
+    acc2 = khg.AccumAmDiagGmm()
+    acc2.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    ali = np.asarray(r["alignment"], np.int32)
+    pdfs = [tm.transition_id_to_pdf(int(t)) for t in ali]
+    f = feats[n - 1]
+    for t in range(8):
+        acc2.accumulate_for_gmm(model=am, data=f[t], gmm_index=pdfs[t], weight=1.0)
+    t0 = time.perf_counter()
+    for t in range(f.shape[0]):
+        acc2.accumulate_for_gmm(model=am, data=f[t], gmm_index=pdfs[t], weight=1.0)
+    dt = time.perf_counter() - t0
+    print(f"per-frame accumulate_for_gmm: {1e3 * dt / f.shape[0]:.3f} ms per frame = {f.shape[0] / dt:.0f} frames/s")
 
 
 if __name__ == "__main__":
