@@ -42,6 +42,9 @@ int khg_version(void);
 /* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL to let the
  * context create its own non-blocking stream. */
 int khg_ctx_create(int device, void *stream, khg_ctx **out);
+/* Waits for the context's streams.  Handles made on the context (models, tables, utterance sets, statistics blocks) may be destroyed
+ * after it; their device memory stays valid until then (a statistics block can still be read through another context), and every
+ * entry point that is given the destroyed context returns KHG_E_ARG. */
 int khg_ctx_destroy(khg_ctx *ctx);
 /* Waits for the stream and reports kernel-side errors deferred by the asynchronous entry points
  * (khg_loglikes, khg_align without host outputs, khg_acc_stats): KHG_E_RUNTIME where the reference

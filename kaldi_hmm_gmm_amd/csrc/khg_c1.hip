@@ -97,7 +97,7 @@ int accs_allreduce_pieces(khg_ctx* ctx, khg_accs* a, const khg_model* m, int fir
   return KHG_OK;
 }
 extern "C" int khg_accs_allreduce_range(khg_ctx* ctx, khg_accs* a, const khg_model* m, int32_t first_pdf, int32_t n_pdf, void* comm) {
-  if (!ctx || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_range: bad arguments");
+  if (ctx_dead(ctx) || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_range: bad arguments");
   if (a->sumG != m->sumG || a->D != m->D) return khg_set_error(KHG_E_RUNTIME, "khg_accs_allreduce_range: accumulator / model layouts differ");
   if (!comm) return KHG_OK;
   return accs_allreduce_pieces(ctx, a, m, first_pdf, n_pdf, comm, ctx->stream);
@@ -111,7 +111,7 @@ extern "C" int khg_comm_unique_id(void* id_out) {
   return r ? rccl_fail("ncclGetUniqueId", r) : KHG_OK;
 }
 extern "C" int khg_comm_create(khg_ctx* ctx, int32_t nranks, int32_t rank, const void* id, void** comm_out) {
-  if (!ctx || !id || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_comm_create: bad arguments");
+  if (ctx_dead(ctx) || !id || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_comm_create: bad arguments");
   int rc = rccl_bind();
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
@@ -141,7 +141,7 @@ extern "C" int khg_comm_destroy(void* comm) {
   return r ? rccl_fail("ncclCommDestroy", r) : KHG_OK;
 }
 extern "C" int khg_accs_allreduce(khg_ctx* ctx, khg_accs* a, void* comm) {
-  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce: bad arguments");
+  if (ctx_dead(ctx) || !a) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce: bad arguments");
   if (!comm) return KHG_OK;
   int rc = rccl_bind();
   if (rc) return rc;
@@ -150,7 +150,7 @@ extern "C" int khg_accs_allreduce(khg_ctx* ctx, khg_accs* a, void* comm) {
   return r ? rccl_fail("ncclAllReduce", r) : KHG_OK;
 }
 extern "C" int khg_accs_allreduce_f32(khg_ctx* ctx, khg_accs* a, void* comm) {
-  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_f32: bad arguments");
+  if (ctx_dead(ctx) || !a) return khg_set_error(KHG_E_ARG, "khg_accs_allreduce_f32: bad arguments");
   if (comm) { int rc = rccl_bind(); if (rc) return rc; }
   if (a->wire_cap < a->n) {
     DEVFREE(a->wire_d);

@@ -55,8 +55,20 @@ bool khg_ctx_alive(const khg_ctx* ctx) {
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   return std::find(g_ctxs.begin(), g_ctxs.end(), ctx) != g_ctxs.end();
 }
+// Scratch blocks of destroyed contexts that utterance sets still point into (a handle may be destroyed after its context): kept until
+// the last of those sets lets go, so that no later context's block can take the same addresses while stale pointers exist.
+static std::vector<KhgArena> g_orphans;
 bool khg_arena_release(void* p) {
   std::lock_guard<std::mutex> lk(g_ctx_mu);
+  for (size_t z = 0; z < g_orphans.size(); ++z) {
+    KhgArena& a = g_orphans[z];
+    if (!a.owns(p)) continue;
+    const size_t off = (size_t)((char*)p - a.dev);
+    for (size_t i = a.blocks.size(); i-- > 0;)
+      if (a.blocks[i].first == off) { a.blocks.erase(a.blocks.begin() + (long)i); break; }
+    if (a.blocks.empty()) { (void)hipFree(a.dev); (void)hipHostFree(a.host); g_orphans.erase(g_orphans.begin() + (long)z); }
+    return true;
+  }
   for (khg_ctx* c : g_ctxs) {
     KhgArena& a = c->arena;
     if (!a.owns(p)) continue;
@@ -109,7 +121,15 @@ extern "C" int khg_ctx_destroy(khg_ctx* c) {
   if (!c) return KHG_OK;
   (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->sides) (void)hipStreamSynchronize(s);
-  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
+    if (c->arena.dev && !c->arena.blocks.empty()) {        // small sets outlive the context: their scratch stays until they go (g_orphans)
+      c->arena.dirty.clear();
+      g_orphans.push_back(std::move(c->arena));
+      c->arena = KhgArena();
+    }
+  }
   DEVFREE(c->err_flag_d); DEVFREE(c->dump_d);
   if (c->err_host) (void)hipHostFree(c->err_host);
   if (c->arena.dev) (void)hipFree(c->arena.dev);
@@ -473,7 +493,7 @@ khg_model* khg_model_lookup(uint64_t serial) {
 
 extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_t* gauss_off,
                                 const float* gconsts, const float* miv, const float* iv, khg_model** out) {
-  if (!ctx || !out || P <= 0 || D <= 0 || !gauss_off || !gconsts || !miv || !iv)
+  if (ctx_dead(ctx) || !out || P <= 0 || D <= 0 || !gauss_off || !gconsts || !miv || !iv)
     return khg_set_error(KHG_E_ARG, "khg_model_create: bad arguments");
   if (D > KHG_MAX_DIM) return khg_set_error(KHG_E_UNSUPPORTED, "khg_model_create: feature dim > " + std::to_string(KHG_MAX_DIM) + " is not supported (a 64-frame chunk of rows must fit LDS)");
   if (gauss_off[0] != 0) return khg_set_error(KHG_E_ARG, "khg_model_create: gauss_off[0] != 0");
@@ -522,7 +542,7 @@ extern "C" int khg_model_destroy(khg_model* m) {
 
 // ------------------------------------------------------------------------------------------
 extern "C" int khg_tm_create(khg_ctx* ctx, int32_t num_tids, const int32_t* id2pdf, khg_tm** out) {
-  if (!ctx || !out || num_tids <= 0 || !id2pdf) return khg_set_error(KHG_E_ARG, "khg_tm_create: bad arguments");
+  if (ctx_dead(ctx) || !out || num_tids <= 0 || !id2pdf) return khg_set_error(KHG_E_ARG, "khg_tm_create: bad arguments");
   khg_tm* t = new khg_tm();
   t->ctx = ctx; t->num_tids = num_tids;
   t->id2pdf.assign(id2pdf, id2pdf + num_tids + 1);

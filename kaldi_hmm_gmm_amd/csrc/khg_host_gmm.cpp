@@ -874,8 +874,11 @@ void AccumAmDiagGmm::Flush() const {
   int64_t n = 0;
   CApi(khg_accs_size(d.h, &n));
   std::vector<double> buf((size_t)n);
-  CApi(khg_accs_download(d.ctx, d.h, buf.data()));
-  CApi(khg_accs_zero(d.ctx, d.h));
+  // (the block is plain device memory: if its context was closed meanwhile -- khg_ctx_destroy waited for its streams -- the sums are
+  //  still there and the current default context's stream can fetch them)
+  khg_ctx* c = d.ctx;
+  if (khg_accs_download(c, d.h, buf.data()) != KHG_OK) { c = DefaultCtx(); CApi(khg_accs_download(c, d.h, buf.data())); }
+  CApi(khg_accs_zero(c, d.h));
   const size_t sumG = (size_t)d.gauss_off.back(), D = (size_t)d.D;
   const size_t sc = sumG + 2 * sumG * D + (size_t)d.num_tids + 1;
   d.pending = false; d.seen_frames = 0.0; d.seen_ll = 0.0;

@@ -72,6 +72,9 @@ bool khg_arena_release(void* p);                           // true when p came f
 void khg_dev_free(void* p);                                // arena or hipFree
 void arena_mark_dirty(khg_ctx* ctx, const void* dev_ptr, size_t bytes);
 bool khg_ctx_alive(const khg_ctx* ctx);                    // khg_ctx_model.hip: the context has not been destroyed (handles may outlive it)
+// First argument check of every entry point that takes a context: null, or destroyed while a caller (a host object's cached device
+// handle, say) still held the pointer -> KHG_E_ARG instead of a use after free.
+static inline bool ctx_dead(const khg_ctx* ctx) { return !ctx || !khg_ctx_alive(ctx); }
 // Every kernel launch of the library goes through this: uploads staged in the arena since the last launch reach the device first.
 #define KHG_LAUNCH(ctx_, ...) do { (void)arena_flush(ctx_); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled); staged uploads go out first

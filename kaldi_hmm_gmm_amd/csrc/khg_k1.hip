@@ -670,7 +670,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
 }
 
 static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reach) {
-  if (!ctx || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
+  if (ctx_dead(ctx) || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
   if (u->pdf_first.size() != u->pdfs.size()) reach = 0;
   const bool reachable_only = reach != 0;
   u->ll_mode = reachable_only ? 1 : 0;
@@ -781,7 +781,7 @@ extern "C" int khg_loglikes_layout(const khg_utts* u, int64_t* ll_off, int64_t* 
   return KHG_OK;
 }
 extern "C" int khg_loglikes_download(khg_ctx* ctx, const khg_utts* u, float* ll) {
-  if (!ctx || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
   if (!u->ll_valid) return khg_set_error(KHG_E_ARG, "khg_loglikes_download: call khg_loglikes first");
   int rc = check_err_flag(ctx, "khg_loglikes");
   if (rc) return rc;
@@ -790,7 +790,7 @@ extern "C" int khg_loglikes_download(khg_ctx* ctx, const khg_utts* u, float* ll)
   return KHG_OK;
 }
 extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
-  if (!ctx || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
   int rc = wait_ali(ctx, u);
   if (rc) return rc;
   if (!u->pdf_off_d) {

@@ -32,7 +32,7 @@ static int ensure_ali(khg_ctx* ctx, khg_utts* u) {
 extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_align_config* cfg,
                          int32_t* ali_h, int32_t* words_h, int64_t* words_off_h, int64_t words_cap,
                          float* like_h, int32_t* status_h) {
-  if (!ctx || !tm || !u || !cfg) return khg_set_error(KHG_E_ARG, "khg_align: bad arguments");
+  if (ctx_dead(ctx) || !tm || !u || !cfg) return khg_set_error(KHG_E_ARG, "khg_align: bad arguments");
   if (!u->has_graphs) return khg_set_error(KHG_E_ARG, "khg_align: the utterance set has no decoding graphs");
   if (!u->ll_valid) return khg_set_error(KHG_E_ARG, "khg_align: call khg_loglikes first");
   // decoder-wrappers.cc:29-33
@@ -273,7 +273,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
 }
 
 extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
-  if (!ctx || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
   int rc = wait_ali(ctx, u);
   if (!rc) rc = ensure_ali(ctx, u);
   if (rc) return rc;
@@ -288,7 +288,7 @@ extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
 }
 
 extern "C" int khg_ali_download(khg_ctx* ctx, khg_utts* u, int32_t* ali) {
-  if (!ctx || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
   if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_ali_download: no resident alignment");
   int rc = wait_ali(ctx, u);
   if (!rc) rc = check_err_flag(ctx, "khg_align");

@@ -9,7 +9,7 @@
 // ------------------------------------------------------------------------------------------
 // accumulators + K3
 extern "C" int khg_accs_create(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_accs** out) {
-  if (!ctx || !m || !tm || !out) return khg_set_error(KHG_E_ARG, "khg_accs_create: bad arguments");
+  if (ctx_dead(ctx) || !m || !tm || !out) return khg_set_error(KHG_E_ARG, "khg_accs_create: bad arguments");
   khg_accs* a = new khg_accs();
   a->ctx = ctx; a->sumG = m->sumG; a->D = m->D; a->num_tids = tm->num_tids;
   a->n = a->sumG * (1 + 2 * (int64_t)a->D) + a->num_tids + 1 + 8;
@@ -21,21 +21,21 @@ extern "C" int khg_accs_create(khg_ctx* ctx, const khg_model* m, const khg_tm* t
 }
 extern "C" int khg_accs_destroy(khg_accs* a) { if (a) { DEVFREE(a->buf_d); DEVFREE(a->wire_d); delete a; } return KHG_OK; }
 extern "C" int khg_accs_zero(khg_ctx* ctx, khg_accs* a) {
-  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !a) return khg_set_error(KHG_E_ARG, "bad arguments");
   HIPCHK(hipMemsetAsync(a->buf_d, 0, sizeof(double) * (size_t)a->n, ctx->stream));
   return KHG_OK;
 }
 extern "C" int khg_accs_size(const khg_accs* a, int64_t* n) { if (!a || !n) return khg_set_error(KHG_E_ARG, "bad arguments"); *n = a->n; return KHG_OK; }
 extern "C" int khg_accs_device_ptr(const khg_accs* a, void** p) { if (!a || !p) return khg_set_error(KHG_E_ARG, "bad arguments"); *p = a->buf_d; return KHG_OK; }
 extern "C" int khg_accs_download(khg_ctx* ctx, const khg_accs* a, double* buf) {
-  if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
   { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(buf, a->buf_d, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return KHG_OK;
 }
 extern "C" int khg_accs_upload(khg_ctx* ctx, khg_accs* a, const double* buf) {
-  if (!ctx || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
+  if (ctx_dead(ctx) || !a || !buf) return khg_set_error(KHG_E_ARG, "bad arguments");
   HIPCHK(hipMemcpyAsync(a->buf_d, buf, sizeof(double) * (size_t)a->n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return KHG_OK;
@@ -101,7 +101,7 @@ static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use)
 }
 
 static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
-  if (!ctx || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
+  if (ctx_dead(ctx) || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
   if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
   if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
     return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");

@@ -8,7 +8,7 @@
 // ------------------------------------------------------------------------------------------
 // K4: device M-step
 extern "C" int khg_model_set_weights(khg_ctx* ctx, khg_model* m, const float* weights) {
-  if (!ctx || !m || !weights) return khg_set_error(KHG_E_ARG, "khg_model_set_weights: bad arguments");
+  if (ctx_dead(ctx) || !m || !weights) return khg_set_error(KHG_E_ARG, "khg_model_set_weights: bad arguments");
   if (!m->weights_d) { int rc = dev_alloc(&m->weights_d, (size_t)m->sumG); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(m->weights_d, weights, sizeof(float) * (size_t)m->sumG, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -22,7 +22,7 @@ extern "C" int khg_model_num_gauss(const khg_model* m, int64_t* total, int32_t* 
   return KHG_OK;
 }
 extern "C" int khg_model_download(khg_ctx* ctx, const khg_model* m, float* weights, float* gconsts, float* miv, float* iv) {
-  if (!ctx || !m) return khg_set_error(KHG_E_ARG, "khg_model_download: bad arguments");
+  if (ctx_dead(ctx) || !m) return khg_set_error(KHG_E_ARG, "khg_model_download: bad arguments");
   if (weights && !m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_download: the model has no weights (khg_model_set_weights)");
   const size_t G = (size_t)m->sumG, n = G * m->D;
   if (weights) HIPCHK(hipMemcpyAsync(weights, m->weights_d, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream));
@@ -37,7 +37,7 @@ extern "C" int khg_model_download(khg_ctx* ctx, const khg_model* m, float* weigh
 //   rows:    k4_mle_update on pdfs [p0, p0 + np): their parameter rows are rewritten in place (old layout), one K4Res per pdf;
 //   finish:  totals in pdf order, compaction when some pdf lost Gaussians, the K1 / K3 images -- on the complete rows + results.
 static int mle_update_rows(khg_ctx* ctx, khg_model* m, const khg_accs* acc, const khg_mle_options* o, uint16_t flags, int p0, int np) {
-  if (!ctx || !m || !acc || !o) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: bad arguments");
+  if (ctx_dead(ctx) || !m || !acc || !o) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: bad arguments");
   if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_mle_update: the model has no weights (khg_model_set_weights)");
   if (acc->D != m->D || acc->sumG != m->sumG)
     return khg_set_error(KHG_E_RUNTIME, "khg_model_mle_update: accumulator / model dimensions do not match");
@@ -83,7 +83,7 @@ static int mle_update_rows(khg_ctx* ctx, khg_model* m, const khg_accs* acc, cons
 }
 static int mle_update_finish(khg_ctx* ctx, khg_model* m, float* objf_change, float* count, int32_t* floored_elems, int32_t* floored_gauss,
                              int32_t* removed) {
-  if (!ctx || !m || !m->k4_res_d || m->k4_res_P != m->P) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_finish: no update in progress");
+  if (ctx_dead(ctx) || !m || !m->k4_res_d || m->k4_res_P != m->P) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_finish: no update in progress");
   const int P = m->P, D = m->D;
   std::vector<K4Res> res((size_t)P);
   hipError_t e = hipMemcpyAsync(res.data(), m->k4_res_d, sizeof(K4Res) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream);
@@ -156,7 +156,7 @@ extern "C" int khg_model_mle_update_finish(khg_ctx* ctx, khg_model* m, float* ob
 // the rows an update of pdfs [first_pdf, first_pdf + n_pdf) rewrote + its per-pdf results (32 bytes each), to / from the host: the
 // exchange step of the sharded M-step for callers whose ranks cannot share device buffers (the tests' gloo ranks on one GPU)
 static int mle_rows_copy(khg_ctx* ctx, khg_model* m, int p0, int np, float* w, float* gc, float* miv, float* iv, void* res, bool up) {
-  if (!ctx || !m || p0 < 0 || np < 0 || p0 + np > m->P || !m->k4_res_d || m->k4_res_P != m->P)
+  if (ctx_dead(ctx) || !m || p0 < 0 || np < 0 || p0 + np > m->P || !m->k4_res_d || m->k4_res_P != m->P)
     return khg_set_error(KHG_E_ARG, "khg_model_mle_rows: bad arguments (or no update in progress)");
   const size_t g0 = (size_t)m->gauss_off[p0], ng = (size_t)m->gauss_off[p0 + np] - g0, D = (size_t)m->D;
   auto cp = [&](float* host, float* dev, size_t n) -> hipError_t {
@@ -192,7 +192,7 @@ extern "C" int khg_model_mle_rows_upload(khg_ctx* ctx, khg_model* m, int32_t fir
 extern "C" int khg_model_mle_update_sharded(khg_ctx* ctx, khg_model* m, khg_accs* acc, const khg_mle_options* o, uint16_t flags,
                                             void* comm, int32_t nranks, int32_t rank, float* objf_change, float* count,
                                             int32_t* floored_elems, int32_t* floored_gauss, int32_t* removed) {
-  if (!ctx || !m || !acc || !o || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_sharded: bad arguments");
+  if (ctx_dead(ctx) || !m || !acc || !o || nranks < 1 || rank < 0 || rank >= nranks) return khg_set_error(KHG_E_ARG, "khg_model_mle_update_sharded: bad arguments");
   if (!comm) {                      // (a one-rank communicator still goes through RCCL: reductions and broadcasts to itself)
     int rc = mle_update_rows(ctx, m, acc, o, flags, 0, m->P);
     return rc ? rc : mle_update_finish(ctx, m, objf_change, count, floored_elems, floored_gauss, removed);
@@ -245,7 +245,7 @@ extern "C" int khg_model_mle_update_sharded(khg_ctx* ctx, khg_model* m, khg_accs
 }
 
 extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* targets, float perturb, const float* randn, int64_t n_randn) {
-  if (!ctx || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_split: bad arguments");
+  if (ctx_dead(ctx) || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_split: bad arguments");
   if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_split: the model has no weights (khg_model_set_weights)");
   const int P = m->P, D = m->D;
   std::vector<int32_t> new_off((size_t)P + 1, 0);
@@ -301,7 +301,7 @@ extern "C" int khg_model_split(khg_ctx* ctx, khg_model* m, const int32_t* target
 // AmDiagGmm::MergeByCount's per-pdf DiagGmm::Merge (csrc/am-diag-gmm.cc:91-108, csrc/diag-gmm.cc:557-759) on the device model:
 // pdf p keeps targets[p] components (1 <= targets[p] <= its count).  Nothing crosses PCIe but the offsets.
 extern "C" int khg_model_merge(khg_ctx* ctx, khg_model* m, const int32_t* targets) {
-  if (!ctx || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_merge: bad arguments");
+  if (ctx_dead(ctx) || !m || !targets) return khg_set_error(KHG_E_ARG, "khg_model_merge: bad arguments");
   if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_merge: the model has no weights (khg_model_set_weights)");
   const int P = m->P, D = m->D;
   std::vector<int32_t> new_off((size_t)P + 1, 0);
@@ -363,7 +363,7 @@ extern "C" int khg_model_merge(khg_ctx* ctx, khg_model* m, const int32_t* target
 
 // After khg_model_mle_update removed Gaussians the accumulator block is laid out for fewer rows.
 extern "C" int khg_accs_relayout(khg_ctx* ctx, khg_accs* a, const khg_model* m) {
-  if (!ctx || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_relayout: bad arguments");
+  if (ctx_dead(ctx) || !a || !m) return khg_set_error(KHG_E_ARG, "khg_accs_relayout: bad arguments");
   if (m->D != a->D) return khg_set_error(KHG_E_RUNTIME, "khg_accs_relayout: dimension mismatch");
   const int64_t n = m->sumG * (1 + 2 * (int64_t)a->D) + a->num_tids + 1 + 8;
   if (n > a->cap) {
@@ -376,7 +376,7 @@ extern "C" int khg_accs_relayout(khg_ctx* ctx, khg_accs* a, const khg_model* m) 
   return khg_accs_zero(ctx, a);
 }
 extern "C" int khg_accs_download_trans(khg_ctx* ctx, const khg_accs* a, double* trans, double* scalars) {
-  if (!ctx || !a) return khg_set_error(KHG_E_ARG, "khg_accs_download_trans: bad arguments");
+  if (ctx_dead(ctx) || !a) return khg_set_error(KHG_E_ARG, "khg_accs_download_trans: bad arguments");
   if (!trans && scalars) {      // the per-utterance call pattern reads only the totals: one pinned copy in front of the error word's
     double* land = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->err_host) + 64);
     HIPCHK(hipMemcpyAsync(land, a->scalars(), sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -392,7 +392,7 @@ extern "C" int khg_accs_download_trans(khg_ctx* ctx, const khg_accs* a, double* 
   return KHG_OK;
 }
 extern "C" int khg_accs_download_range(khg_ctx* ctx, const khg_accs* a, int64_t first, int64_t count, double* dst) {
-  if (!ctx || !a || !dst || first < 0 || count < 0 || first + count > a->n) return khg_set_error(KHG_E_ARG, "khg_accs_download_range: bad arguments");
+  if (ctx_dead(ctx) || !a || !dst || first < 0 || count < 0 || first + count > a->n) return khg_set_error(KHG_E_ARG, "khg_accs_download_range: bad arguments");
   { int rc = check_err_flag(ctx, "khg_acc_stats"); if (rc) return rc; }
   if (count) HIPCHK(hipMemcpyAsync(dst, a->buf_d + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -400,7 +400,7 @@ extern "C" int khg_accs_download_range(khg_ctx* ctx, const khg_accs* a, int64_t 
 }
 
 extern "C" int khg_model_scale_weights(khg_ctx* ctx, khg_model* m, int32_t n, const int32_t* pdfs, float scale) {
-  if (!ctx || !m || n < 0 || (n > 0 && !pdfs)) return khg_set_error(KHG_E_ARG, "khg_model_scale_weights: bad arguments");
+  if (ctx_dead(ctx) || !m || n < 0 || (n > 0 && !pdfs)) return khg_set_error(KHG_E_ARG, "khg_model_scale_weights: bad arguments");
   if (!m->has_weights) return khg_set_error(KHG_E_ARG, "khg_model_scale_weights: the model has no weights (khg_model_set_weights)");
   if (n == 0) return KHG_OK;
   std::vector<int32_t> v(pdfs, pdfs + n);

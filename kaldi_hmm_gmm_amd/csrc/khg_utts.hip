@@ -17,7 +17,7 @@ extern "C" int khg_utts_create(khg_ctx* ctx, const khg_tm* tm, int32_t n_utt, in
                                const int64_t* state_off, const int32_t* start, const int64_t* arc_off,
                                const int32_t* ilabel, const int32_t* olabel, const float* weight,
                                const int32_t* nextstate, const float* final_w, khg_utts** out) {
-  if (!ctx || !out || n_utt <= 0 || D <= 0 || !frame_off || (!feats_h && !feats_dv))
+  if (ctx_dead(ctx) || !out || n_utt <= 0 || D <= 0 || !frame_off || (!feats_h && !feats_dv))
     return khg_set_error(KHG_E_ARG, "khg_utts_create: bad arguments");
   if (frame_off[0] != 0) return khg_set_error(KHG_E_ARG, "khg_utts_create: frame_off[0] != 0");
   for (int i = 0; i < n_utt; ++i)

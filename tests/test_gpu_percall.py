@@ -313,3 +313,49 @@ def test_per_frame_accumulate_is_the_same_device_block(khg, ctx):
     assert llh == pytest.approx(ll0, abs=2e-4)
     assert c.tot_count == pytest.approx(0.5) and c.tot_log_like == pytest.approx(0.5 * llh, rel=1e-5)
     assert float(np.sum(c.get_acc(5).occupancy)) == pytest.approx(0.5, rel=1e-5)
+
+
+def test_a_closed_context_is_an_error_and_loses_nothing(khg, ctx):
+    """The host objects cache device handles (the model, the transition table, the statistics block) made on the default context.
+    Closing that context under them must neither crash nor lose pending statistics: entry points refuse a destroyed context
+    (RuntimeError), the statistics block is plain device memory that the next default context can still read, the model is
+    uploaded again for the new context, and a small set that outlives its context keeps its scratch until it goes."""
+    from kaldi_hmm_gmm_amd import _gpu
+    P, G, D = 90, 8, 13
+    m = synth.make_model(P, G, D, seed=31)
+    ut = synth.make_utts(m, 2, seed=8, min_phones=3, max_phones=6)
+    am, tm = synth.host_objects(m)
+    cfg = khg.AlignConfig(beam=200.0, retry_beam=0.0, careful=False)
+
+    def one(u, accs):
+        f0, f1 = int(ut.frame_off[u]), int(ut.frame_off[u + 1])
+        feats = np.ascontiguousarray(ut.feats[f0:f1])
+        r = khg.gmm_align_compiled(am_gmm=am, transition_model=tm, utt=str(u), fst=synth.utt_fst(ut.graphs, u), feats=feats, align_config=cfg,
+                                   acoustic_scale=0.1, transition_scale=1.0, self_loop_scale=0.1)
+        khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=accs, transition_model=tm, feats=feats, ali=r["alignment"], transition_accs=None)
+        return r["alignment"], f1 - f0
+
+    want = khg.AccumAmDiagGmm(); want.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    ali_want = [one(u, want)[0] for u in range(2)]
+
+    ctx2 = khg.Context(0)
+    try:
+        _gpu.set_default_context(ctx2)
+        accs = khg.AccumAmDiagGmm(); accs.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+        ali0, n0 = one(0, accs)
+        assert accs._has_device_stats
+        orphan = khg.UtteranceSet(ctx2, None, np.array([0, 40], np.int64), np.ascontiguousarray(ut.feats[:40]))   # a small set left alive
+        ctx2.close()
+        with pytest.raises(RuntimeError):
+            one(1, accs)                                   # the default context is gone: an error, not a use after free
+    finally:
+        _gpu.set_default_context(ctx)
+    ali1, n1 = one(1, accs)                                # new context: the model goes up again, the pending block is read through it
+    assert ali0 == ali_want[0] and ali1 == ali_want[1]
+    assert accs.tot_count == pytest.approx(n0 + n1) and accs.tot_count == pytest.approx(want.tot_count)
+    assert accs.tot_log_like == pytest.approx(want.tot_log_like, rel=1e-6)
+    for p in range(0, P, 11):
+        np.testing.assert_allclose(accs.get_acc(p).mean_accumulator, want.get_acc(p).mean_accumulator, rtol=2e-5, atol=1e-4)
+    before = ctx.get_option("scratch_blocks")
+    orphan.close()                                         # its scratch belonged to the closed context: released there, not in this one
+    assert ctx.get_option("scratch_blocks") == before
