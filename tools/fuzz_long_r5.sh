@@ -1,16 +1,17 @@
 #!/bin/bash
-# Long randomised sweeps on the final sources (tests/fuzzlib.py), 1500 s each -> gpurun_out/r5_fuzz_*_1500.txt
+# Long randomised sweeps on the final sources (tests/fuzzlib.py), $1 seconds each (default 1500; seeds move with $2) -> gpurun_out/r5_fuzz_*_<seconds>.txt
 cd "$GRAFT_REPO_ROOT"
+SECS=${1:-1500}; SEED=${2:-0}
 for what in parity graphs; do
-python - > gpurun_out/r5_fuzz_${what}_1500.txt 2>&1 <<PY
+python - > gpurun_out/r5_fuzz_${what}_${SECS}.txt 2>&1 <<PY
 import sys
 sys.path.insert(0, "tests")
 import fuzzlib
 from kaldi_hmm_gmm_amd import Context
 ctx = Context(0)
 f = fuzzlib.fuzz_parity if "$what" == "parity" else fuzzlib.fuzz_graphs
-print("$what fuzz ok:", f(ctx, budget=1500.0, seed=9511 if "$what" == "parity" else 9512))
+print("$what fuzz ok:", f(ctx, budget=float($SECS), seed=$SEED + (9511 if "$what" == "parity" else 9512)))
 PY
-tail -n 1 gpurun_out/r5_fuzz_${what}_1500.txt
+tail -n 1 gpurun_out/r5_fuzz_${what}_${SECS}.txt
 done
 python tools/fallback_stress.py > gpurun_out/r5_fallback_stress.txt 2>&1; tail -n 5 gpurun_out/r5_fallback_stress.txt
