@@ -1061,7 +1061,8 @@ def main():
         if out["c1_pipelined_parts"]:
             out["allreduce_note"] = ("allreduce_ms_per_step spans the LAST set's K3 with the exchange pipelined behind it in %d pdf ranges "
                                      "(khg_acc_stats_reduce); the RCCL pieces alone are kernel_ms_per_step['c1_allreduce']" % args.c1_parts)
-        if not args.no_cpu_baseline:               # rank 0, whatever N (the other ranks wait at the closing barrier)
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline belongs to the N = 1 line only: at N > 1 the other ranks would sit
+                                                          # at the closing barrier for its 15 s (and the oracle check that rides on it)
             ncpu = min(n_local, 40000)     # enough work for a few seconds of every host core
             fh = feats[: int(ut.frame_off[ncpu])].cpu().numpy()
             ans, out["cpu_baseline"] = cpu_baseline(model, gc, ut, cost, {"n": ncpu, "feats": fh}, args.cpu_baseline_seconds,
@@ -1071,7 +1072,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["recipe_beam_line"] = recipe_line
-        if args.per_call_utts > 0:
+        if args.per_call_utts > 0 and world == 1:
             out["per_call_line"] = per_call_line(args, model, ut, feats, D, ctxs[0], out.get("cpu_baseline"))
         record = json.dumps(out)
     if dist_on:
