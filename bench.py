@@ -89,11 +89,33 @@ def self_launch(args):
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + base + extra
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the launcher and its ranks form their own process group: a rung that times out is ended as a GROUP (the elastic agent, if
+        # killed alone, cannot reap ranks hung in RCCL -- they would keep the GPUs and the pipes while the next rung starts)
+        import signal
+        pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
-            rc, out, err = r.returncode, r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
-        except subprocess.TimeoutExpired as ex:
-            rc, out, err = 124, (ex.stdout or b"").decode("utf-8", "replace"), (ex.stderr or b"").decode("utf-8", "replace") + f"\n[self_launch] timed out after {timeout} s"
+            o, e = pr.communicate(timeout=timeout)
+            rc, out, err = pr.returncode, o.decode("utf-8", "replace"), e.decode("utf-8", "replace")
+        except subprocess.TimeoutExpired:
+            for sig, grace in ((signal.SIGTERM, 20), (signal.SIGKILL, 20)):
+                try:
+                    os.killpg(pr.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    pr.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)      # ranks that outlived the agent
+            except ProcessLookupError:
+                pass
+            try:
+                o, e = pr.communicate(timeout=20)
+            except Exception:
+                o, e = b"", b""
+            rc, out, err = 124, o.decode("utf-8", "replace"), e.decode("utf-8", "replace") + f"\n[self_launch] timed out after {timeout} s"
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
         return rc, (lines[-1] if lines else None), err
 

@@ -99,7 +99,9 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_K2_INORDER 6     /* 1: K2 workgroups in utterance order instead of longest first                  [KHG_K2_INORDER] */
 #define KHG_OPT_K2_KS 7          /* states per thread on K2's register-resident path: 0 auto, 2, 4; 3 = the general three-slot kernel also where the two-slot one applies [KHG_K2_KS] */
 #define KHG_OPT_K2_SERIAL 8      /* 1: the one-lane order-faithful decoder also where the wave form applies;
-                                    2: the wave form with its graph tables in HBM scratch also where they fit LDS     [KHG_K2_SERIAL] */
+                                    2: the wave form with its graph tables in HBM scratch also where they fit LDS;
+                                    3: the general wave form also where the chain form (no epsilon arcs, <= 1000 states,
+                                       out-degree <= 4) applies                                                      [KHG_K2_SERIAL] */
 #define KHG_OPT_K2_PROF 9        /* 1: per-utterance cycle stamps of K2 to stderr                                 [KHG_K2_PROF] */
 #define KHG_OPT_K3_BUCKET 10     /* frames by pdf: 0 stable radix sort of (pdf, frame) pairs (rocPRIM; reproducible sums), 1 atomic cursor scatter, 2 the library's own stable counting sort (same order as 0, slower) [KHG_K3_BUCKET=sort|atomic|count] */
 #define KHG_OPT_K3_FORM 11       /* 0 auto, 1 the chunk-per-block MFMA form for every shape, 2 the VALU form      [KHG_K3_FORM=block, KHG_K3_VALU=1] */

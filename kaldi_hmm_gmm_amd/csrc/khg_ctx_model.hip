@@ -168,7 +168,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 2}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 3}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
@@ -224,6 +224,9 @@ extern "C" int khg_ctx_sync(khg_ctx* c) {
 }
 // read-and-clear the device error word; maps bits to the reference's exceptions
 int check_err_flag(khg_ctx* c, const char* where) {
+  // every download of the library passes here first: uploads still staged in the arena's mirror reach the device before any
+  // plain copy reads (or a later flush overwrites) the bytes they belong to
+  { int rf = arena_flush(c); if (rf) return rf; }
   for (int i = 0; i < khg_ctx::NSIDE; ++i)
     if (c->side_dirty[i]) { HIPCHK(hipStreamSynchronize(c->sides[i])); c->side_dirty[i] = false; }
   HIPCHK(hipMemcpyAsync(c->err_host, c->err_flag_d, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

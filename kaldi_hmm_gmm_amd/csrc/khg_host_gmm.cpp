@@ -876,8 +876,12 @@ void AccumAmDiagGmm::Flush() const {
   std::vector<double> buf((size_t)n);
   // (the block is plain device memory: if its context was closed meanwhile -- khg_ctx_destroy waited for its streams -- the sums are
   //  still there and the current default context's stream can fetch them)
+  //  A deferred kernel error (KHG_E_RUNTIME from the device error word: an invalid answer, a pdf-id out of range) is NOT retried --
+  //  the read clears the word, a second attempt would succeed and add garbage into the host accumulators.
   khg_ctx* c = d.ctx;
-  if (khg_accs_download(c, d.h, buf.data()) != KHG_OK) { c = DefaultCtx(); CApi(khg_accs_download(c, d.h, buf.data())); }
+  int rc = khg_accs_download(c, d.h, buf.data());
+  if (rc == KHG_E_ARG) { c = DefaultCtx(); rc = khg_accs_download(c, d.h, buf.data()); }    // KHG_E_ARG: the context is gone
+  CApi(rc);
   CApi(khg_accs_zero(c, d.h));
   const size_t sumG = (size_t)d.gauss_off.back(), D = (size_t)d.D;
   const size_t sc = sumG + 2 * sumG * D + (size_t)d.num_tids + 1;

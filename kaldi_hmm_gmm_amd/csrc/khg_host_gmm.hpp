@@ -269,7 +269,9 @@ class AccumAmDiagGmm {
   AccumAmDiagGmm(const AccumAmDiagGmm& o) { *this = o; }
   AccumAmDiagGmm& operator=(const AccumAmDiagGmm& o);          // deep copy of the host accumulators (the source's device sums flushed first)
   void Init(const AmDiagGmm& model, int dim /* <= 0: the model's */, int flags);
-  void SetZero(int flags) { DropDevice(); for (auto& a : accs_) a->SetZero(flags); }
+  // csrc/mle-am-diag-gmm.cc:35-39: zeroes the flagged statistics of every pdf and nothing else -- the pending device sums are folded
+  // into the host accumulators first, so the unflagged parts and total_frames_ / total_log_like_ survive as in the reference
+  void SetZero(int flags) { Flush(); for (auto& a : accs_) a->SetZero(flags); }
   int NumAccs() const { return (int)accs_.size(); }
   int Dim() const { return accs_.empty() ? 0 : accs_[0]->Dim(); }
   float TotStatsCount() const;

@@ -75,6 +75,9 @@ bool khg_ctx_alive(const khg_ctx* ctx);                    // khg_ctx_model.hip:
 // First argument check of every entry point that takes a context: null, or destroyed while a caller (a host object's cached device
 // handle, say) still held the pointer -> KHG_E_ARG instead of a use after free.
 static inline bool ctx_dead(const khg_ctx* ctx) { return !ctx || !khg_ctx_alive(ctx); }
+// A SMALL utterance set (scratch in its creator's arena) belongs to that context: staged uploads are flushed by launches on it and
+// khg_utts_destroy waits on its streams only.  Entry points that launch on / copy from a set take this check (-> KHG_E_ARG).
+int utts_foreign_ctx(const khg_ctx* ctx, const struct khg_utts* u, const char* where);     // khg_utts.hip
 // Every kernel launch of the library goes through this: uploads staged in the arena since the last launch reach the device first.
 #define KHG_LAUNCH(ctx_, ...) do { (void)arena_flush(ctx_); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // scoped HIP-event pair around a kernel launch, on the launching stream (only when enabled); staged uploads go out first

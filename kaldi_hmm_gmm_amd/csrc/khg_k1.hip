@@ -671,6 +671,7 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
 
 static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reach) {
   if (ctx_dead(ctx) || !m || !u) return khg_set_error(KHG_E_ARG, "khg_loglikes: bad arguments");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_loglikes"); if (rf) return rf; }
   if (u->pdf_first.size() != u->pdfs.size()) reach = 0;
   const bool reachable_only = reach != 0;
   u->ll_mode = reachable_only ? 1 : 0;
@@ -783,6 +784,7 @@ extern "C" int khg_loglikes_layout(const khg_utts* u, int64_t* ll_off, int64_t* 
 extern "C" int khg_loglikes_download(khg_ctx* ctx, const khg_utts* u, float* ll) {
   if (ctx_dead(ctx) || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
   if (!u->ll_valid) return khg_set_error(KHG_E_ARG, "khg_loglikes_download: call khg_loglikes first");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_loglikes_download"); if (rf) return rf; }
   int rc = check_err_flag(ctx, "khg_loglikes");
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ll, u->ll_d, sizeof(float) * (size_t)u->ll_total, hipMemcpyDeviceToHost, ctx->stream));
@@ -791,6 +793,7 @@ extern "C" int khg_loglikes_download(khg_ctx* ctx, const khg_utts* u, float* ll)
 }
 extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
   if (ctx_dead(ctx) || !u || !ll) return khg_set_error(KHG_E_ARG, "bad arguments");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_loglikes_upload"); if (rf) return rf; }
   int rc = wait_ali(ctx, u);
   if (rc) return rc;
   if (!u->pdf_off_d) {
@@ -800,6 +803,8 @@ extern "C" int khg_loglikes_upload(khg_ctx* ctx, khg_utts* u, const float* ll) {
     if (!rc) rc = u_alloc(u, &u->ll_d, (size_t)u->ll_total);
     if (rc) return rc;
   }
+  rc = arena_flush(ctx);      // (staged uploads first: none may land on the score block after this copy)
+  if (rc) return rc;
   HIPCHK(hipMemcpyAsync(u->ll_d, ll, sizeof(float) * (size_t)u->ll_total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   u->ll_mode = 0; u->band_model = nullptr;      // the caller's scores: every cell as given

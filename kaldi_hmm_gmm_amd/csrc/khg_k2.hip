@@ -33,6 +33,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
                          int32_t* ali_h, int32_t* words_h, int64_t* words_off_h, int64_t words_cap,
                          float* like_h, int32_t* status_h) {
   if (ctx_dead(ctx) || !tm || !u || !cfg) return khg_set_error(KHG_E_ARG, "khg_align: bad arguments");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_align"); if (rf) return rf; }
   if (!u->has_graphs) return khg_set_error(KHG_E_ARG, "khg_align: the utterance set has no decoding graphs");
   if (!u->ll_valid) return khg_set_error(KHG_E_ARG, "khg_align: call khg_loglikes first");
   // decoder-wrappers.cc:29-33
@@ -58,6 +59,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     }
     if (rc) return rc;
   }
+  rc = arena_flush(ctx);      // an alignment staged by khg_ali_upload must not land on top of the cleared block
+  if (rc) return rc;
   HIPCHK(hipMemsetAsync(u->ali_d, 0, sizeof(int32_t) * (size_t)u->N, ctx->stream));
   K2Args a;
   a.frame_off = u->frame_off_d; a.state_off = u->state_off_d; a.start = u->start_d;
@@ -119,7 +122,15 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
                            (u->has_eps ? 4 * (S + A + 1) : 0) + 8 + 8 * ((std::max(A, S * (size_t)odeg_w) + 63) / 64 + 1);
   const size_t lds_w_graph = 8 * (S + 1) + 5 * 4 * A + (u->has_eps ? 4 * (S + 1) + 4 * A : 0) + A + S + 64;
   const int fmode = ctx->opt[KHG_OPT_K2_SERIAL];
-  const bool wave_lds = fmode == 0 && S <= 65535 && lds_w_mut + lds_w_graph <= 160 * 1024;
+  // The chain form (k2_viterbi_faithful_chain: no epsilon-input arcs, <= 1000 states, out-degree <= 4 -- a linear transcript's training
+  // graph): a third of the wave form's latency per frame.  KHG_K2_SERIAL = 3: the general wave form also where the chain form applies.
+  const int odeg_c = (int)std::max<int32_t>(1, u->max_outdeg);
+  const size_t S4 = (S + 3) & ~size_t(3);
+  // token costs x 2 + state keys (24) | token states x 2 (8) | first / winner (8) | GetCutoff array (4) | in-arc offsets (4): 48 per state;
+  // per out-arc slot: parked cost (8) + record (8) + info (4) + ordinal (1); score row; in-arc tables (12 + 2 per arc)
+  const size_t lds_chain = 48 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf + 14 * A + 128;
+  const bool chain = fmode == 0 && !u->has_eps && S <= 1000 && u->max_outdeg <= 4 && lds_chain <= 64 * 1024 && max_npdf <= 32767;
+  const bool wave_lds = (fmode == 0 || fmode == 3) && S <= 65535 && lds_w_mut + lds_w_graph <= 160 * 1024;
   const bool wave_gm = fmode != 1 && !wave_lds && S <= 65535 && lds_w_mut <= 160 * 1024;
   const bool lane_gm = !wave_lds && !wave_gm && lds_f > 160 * 1024;
   // Graphs whose DP tables exceed the 160 KB of LDS (a large decoding graph, not a training graph): the generic DP runs with its
@@ -193,7 +204,15 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   if (rc) return rc;
   {
     KernelTimer kt(ctx, "k2_viterbi_faithful", side);
-    if (wave_gm) {
+    if (chain) {
+#define K2_CHAIN(OD)                                                                                                            \
+  do {                                                                                                                          \
+    if (lds_chain > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_chain<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain)); \
+    KHG_LAUNCH(ctx, k2_viterbi_faithful_chain<OD>, dim3(u->n_utt), dim3(64), lds_chain, side, a, (int)max_npdf);                \
+  } while (0)
+      switch (odeg_c) { case 1: K2_CHAIN(1); break; case 2: K2_CHAIN(2); break; case 3: K2_CHAIN(3); break; default: K2_CHAIN(4); break; }
+#undef K2_CHAIN
+    } else if (wave_gm) {
       if (lds_w_mut > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k2_viterbi_faithful_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w_mut));
       KHG_LAUNCH(ctx, k2_viterbi_faithful_wave<true>, dim3(u->n_utt), dim3(64), lds_w_mut, side, a, u->has_eps ? 1 : 0, odeg_w, (int)max_npdf);
     } else if (wave_lds) {
@@ -274,6 +293,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
 
 extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
   if (ctx_dead(ctx) || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_ali_upload"); if (rf) return rf; }
   int rc = wait_ali(ctx, u);
   if (!rc) rc = ensure_ali(ctx, u);
   if (rc) return rc;
@@ -290,7 +310,9 @@ extern "C" int khg_ali_upload(khg_ctx* ctx, khg_utts* u, const int32_t* ali) {
 extern "C" int khg_ali_download(khg_ctx* ctx, khg_utts* u, int32_t* ali) {
   if (ctx_dead(ctx) || !u || !ali) return khg_set_error(KHG_E_ARG, "bad arguments");
   if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_ali_download: no resident alignment");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_ali_download"); if (rf) return rf; }
   int rc = wait_ali(ctx, u);
+  if (!rc) rc = arena_flush(ctx);           // small sets: an uploaded alignment may still be staged in the pinned mirror
   if (!rc) rc = check_err_flag(ctx, "khg_align");
   if (rc) return rc;
   if (u->N) HIPCHK(hipMemcpyAsync(ali, u->ali_d, sizeof(int32_t) * (size_t)u->N, hipMemcpyDeviceToHost, ctx->stream));

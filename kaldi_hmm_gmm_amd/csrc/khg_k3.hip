@@ -102,6 +102,7 @@ static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use)
 
 static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
   if (ctx_dead(ctx) || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_acc_stats"); if (rf) return rf; }
   if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
   if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
     return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");

@@ -251,6 +251,12 @@ extern "C" int khg_utts_features_changed(khg_utts* u) {
   return KHG_OK;
 }
 
+int utts_foreign_ctx(const khg_ctx* ctx, const khg_utts* u, const char* where) {
+  if (u && u->small && u->ctx != ctx)
+    return khg_set_error(KHG_E_ARG, std::string(where) + ": a small utterance set (<= 16 utterances: scratch in its context's arena) must be used with the context that created it");
+  return KHG_OK;
+}
+
 extern "C" int khg_utts_destroy(khg_utts* u) {
   if (!u) return KHG_OK;
   if (u->small && u->ctx && khg_ctx_alive(u->ctx)) {      // (a handle may be destroyed after its context: nothing is in flight then)

@@ -52,7 +52,10 @@ class SynthModel:
         return self.id2pdf.shape[0] - 1
 
 
-def make_model(num_pdfs, gauss, dim, seed=20230414, ragged=False, self_loop_prob=0.75):
+def make_model(num_pdfs, gauss, dim, seed=20230414, ragged=False, self_loop_prob=0.75, mean_scale=3.0):
+    """mean_scale: spread of the Gaussian means (3.0 = a trained-like model, Gaussians ~27 sigma apart at D = 40).
+    A small spread (0.1 .. 0.3) gives CONFUSABLE pdfs, the regime of a recipe's first realign passes: the best path leaves a narrow
+    beam now and then, the reference's pruning decides the answer and khg_align must follow it token for token."""
     rng = np.random.default_rng(seed)
     if ragged:
         g = rng.integers(max(1, gauss // 2), gauss + 1, size=num_pdfs)
@@ -60,7 +63,7 @@ def make_model(num_pdfs, gauss, dim, seed=20230414, ragged=False, self_loop_prob
         g = np.full(num_pdfs, gauss)
     gauss_off = np.concatenate([[0], np.cumsum(g)]).astype(np.int32)
     sumG = int(gauss_off[-1])
-    means = (3.0 * rng.standard_normal((sumG, dim))).astype(np.float32)
+    means = (mean_scale * rng.standard_normal((sumG, dim))).astype(np.float32)
     var = rng.uniform(0.5, 2.0, size=(sumG, dim)).astype(np.float32)
     w = rng.uniform(0.5, 1.5, size=sumG).astype(np.float32)
     for p in range(num_pdfs):
@@ -246,6 +249,25 @@ def sample_feats_torch(model: SynthModel, frame_pdf, seed, device, chunk=1 << 22
                 out[cur: cur + n] = means[ck] + std[ck] * z[k]
             cur += n
     return out
+
+
+def mismatched_model(model: SynthModel, fraction, seed=0):
+    """The model a recipe's EARLY realign passes work with, in caricature: a copy of `model` (uniform Gaussians per pdf) in which
+    a random `fraction` of the pdfs have traded their parameters among themselves -- sure of itself and wrong there.  Features
+    sampled from `model` and aligned with the copy put path costs hundreds apart wherever a traded pdf is on the graph: a narrow
+    beam then prunes the best path, the reference's answer depends on its pruning order, retries and failures occur."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    P = model.num_pdfs
+    G = int(model.gauss_off[1] - model.gauss_off[0])
+    assert (np.diff(model.gauss_off) == G).all(), "uniform Gaussians per pdf"
+    sel = np.nonzero(rng.random(P) < fraction)[0]
+    perm = np.arange(P)
+    if sel.size > 1:
+        perm[sel] = np.roll(rng.permutation(sel), 1)
+    idx = (perm[:, None] * G + np.arange(G)[None, :]).reshape(-1)
+    return dataclasses.replace(model, weights=model.weights[idx].copy(), means=model.means[idx].copy(), vars=model.vars[idx].copy(),
+                               inv_vars=model.inv_vars[idx].copy(), means_invvars=model.means_invvars[idx].copy())
 
 
 def host_objects(model: SynthModel):

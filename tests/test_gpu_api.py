@@ -374,8 +374,8 @@ def test_faster_decoder_class_like_reference_binding(khg):
 
 
 def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, opt):
-    """The wave-parallel order-faithful decoder (prefix-min pruning, atomic per-state minima, first-insertion
-    list order) against the one-lane emulation and the oracle's FasterDecoder, on scores that make the beam
+    """The wave-parallel order-faithful decoders -- the chain form (one lane per token, DPP prefix-min, parked slots) and the general
+    wave form (prefix-min pruning, atomic per-state minima, first-insertion list order) -- against the one-lane emulation and the oracle's FasterDecoder, on scores that make the beam
     really prune, for the GetCutoff branches (default, max_active, min_active = 0)."""
     m, gc, om, ut, cost = build(120, 2, 10, n_utt=40, seed=33, min_phones=8, max_phones=30)
     dm, tm, us = _dev(ctx, m, gc, ut, cost)
@@ -387,13 +387,16 @@ def test_wave_parallel_faithful_decoder_equals_serial_and_oracle(ctx, opt):
     seen = 0
     for kw in (dict(beam=1.5, retry_beam=6.0), dict(beam=3.0, retry_beam=0.0, max_active=12, min_active=3),
                dict(beam=2.0, retry_beam=8.0, min_active=0), dict(beam=4.0, retry_beam=0.0, max_active=40, min_active=20, beam_delta=0.25)):
-        opt("k2_serial", 0)
+        opt("k2_serial", 0)                   # the chain form (these graphs: no epsilon arcs, out-degree 2)
         rw = us.align(tm, acoustic_scale=1.0, **kw)
-        opt("k2_serial", 1)
+        opt("k2_serial", 3)                   # the general wave form
+        rg = us.align(tm, acoustic_scale=1.0, **kw)
+        opt("k2_serial", 1)                   # the one-lane emulation
         rs = us.align(tm, acoustic_scale=1.0, **kw)
-        assert np.array_equal(rw["status"], rs["status"]), kw
-        assert np.array_equal(rw["ali"], rs["ali"]), kw
-        np.testing.assert_array_equal(rw["like"], rs["like"])
+        for r in (rw, rg):
+            assert np.array_equal(r["status"], rs["status"]), kw
+            assert np.array_equal(r["ali"], rs["ali"]), kw
+            np.testing.assert_array_equal(r["like"], rs["like"])
         seen += int(((rw["status"] & 8) != 0).sum())
         for u in range(0, us.n_utt, 5):
             T = int(ut.frame_off[u + 1] - ut.frame_off[u])

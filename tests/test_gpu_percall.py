@@ -359,3 +359,80 @@ def test_a_closed_context_is_an_error_and_loses_nothing(khg, ctx):
     before = ctx.get_option("scratch_blocks")
     orphan.close()                                         # its scratch belonged to the closed context: released there, not in this one
     assert ctx.get_option("scratch_blocks") == before
+
+
+def test_small_set_staged_alignment_reaches_the_device_before_plain_copies(khg, ctx):
+    """A small set's khg_ali_upload only stages the alignment in the arena's pinned mirror.  Every path that touches the block with a
+    plain copy or memset must flush first: upload -> download with no launch in between returns what was uploaded, and khg_align
+    after an upload is not overwritten by the stale staging (its cleared block + the new answer survive)."""
+    P, G, D = 30, 8, 13
+    m = synth.make_model(P, G, D, seed=5)
+    ut = synth.make_utts(m, 3, seed=3, min_phones=3, max_phones=8)
+    go, gc, _, miv, iv = synth.host_objects(m)[0].flat()
+    dm = khg.DeviceModel(ctx, go, gc, miv, iv)
+    tm = khg.DeviceTransitions(ctx, m.id2pdf)
+    us = khg.UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
+    assert ctx.get_option("scratch_blocks") > 0, "3 utterances: a small (arena-backed) set"
+    N = int(ut.frame_off[-1])
+    fake = (np.arange(N, dtype=np.int32) % m.num_tids) + 1
+    us.upload_ali(fake)
+    np.testing.assert_array_equal(np.asarray(us.download_ali()), fake)
+    fake2 = fake[::-1].copy()
+    us.upload_ali(fake2)                    # staged again ...
+    us.loglikes(dm, reachable_only=True)
+    res = us.align(tm, beam=200.0, acoustic_scale=0.1)       # ... and replaced by the decoder's answer
+    assert not np.any(res["status"] & 1)
+    got = np.asarray(us.download_ali())
+    np.testing.assert_array_equal(got, res["ali"])
+    assert not np.array_equal(got, fake2)
+    us.close(); tm.close(); dm.close()
+
+
+def test_small_set_is_refused_on_a_foreign_context(khg, ctx):
+    """A small set's scratch belongs to its creator's arena (flushes and the destroy-time wait follow that context): launching on it
+    through another live context is KHG_E_ARG -> RuntimeError, not stale reads."""
+    import ctypes as C
+    from kaldi_hmm_gmm_amd import _lib
+    P, G, D = 30, 8, 13
+    m = synth.make_model(P, G, D, seed=5)
+    ut = synth.make_utts(m, 2, seed=3, min_phones=3, max_phones=8)
+    go, gc, _, miv, iv = synth.host_objects(m)[0].flat()
+    ctx2 = khg.Context(0)
+    try:
+        dm2 = khg.DeviceModel(ctx2, go, gc, miv, iv)
+        us = khg.UtteranceSet(ctx, None, ut.frame_off, ut.feats)
+        rc = _lib.lib.khg_loglikes(C.c_void_p(ctx2.h), C.c_void_p(dm2.h), C.c_void_p(us.h))
+        assert rc == -1 and b"context that created it" in _lib.lib.khg_last_error()      # KHG_E_ARG
+        ali = np.ones(int(ut.frame_off[-1]), np.int32)
+        rc = _lib.lib.khg_ali_upload(C.c_void_p(ctx2.h), C.c_void_p(us.h), _lib.ptr(ali, C.c_int32))
+        assert rc == -1
+        us.close(); dm2.close()
+    finally:
+        ctx2.close()
+
+
+def test_set_zero_with_partial_flags_keeps_the_pending_device_sums(khg, ctx):
+    """csrc/mle-am-diag-gmm.cc:35-39: SetZero(flags) zeroes the flagged statistics only.  Statistics still resident on the device
+    are folded in first: after set_zero(kGmmMeans) the occupancies, variance sums and the totals are those accumulated so far."""
+    P, G, D = 60, 8, 13
+    m = synth.make_model(P, G, D, seed=9)
+    ut = synth.make_utts(m, 2, seed=4, min_phones=3, max_phones=6)
+    am, tm = synth.host_objects(m)
+    a = khg.AccumAmDiagGmm(); a.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    b = khg.AccumAmDiagGmm(); b.init(model=am, flags=khg.GmmUpdateFlags.kGmmAll)
+    for acc in (a, b):
+        for u in range(2):
+            f0, f1 = int(ut.frame_off[u]), int(ut.frame_off[u + 1])
+            khg.gmm_acc_stats_ali(am_gmm=am, gmm_accs=acc, transition_model=tm, feats=np.ascontiguousarray(ut.feats[f0:f1]),
+                                  ali=ut.ref_ali[f0:f1].tolist(), transition_accs=None)
+    assert a._has_device_stats
+    a.set_zero(khg.GmmUpdateFlags.kGmmMeans)
+    assert a.tot_count == b.tot_count == float(ut.frame_off[2]) and a.tot_log_like == b.tot_log_like
+    seen = 0.0
+    for p in range(P):
+        x, y = a.get_acc(p), b.get_acc(p)
+        np.testing.assert_array_equal(x.occupancy, y.occupancy)
+        np.testing.assert_array_equal(x.variance_accumulator, y.variance_accumulator)
+        assert not np.any(x.mean_accumulator)
+        seen += float(np.sum(y.occupancy))
+    assert seen == pytest.approx(float(ut.frame_off[2]), rel=1e-6)
