@@ -109,7 +109,10 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_K3_NY 13         /* workgroups per pdf in K3 (0 auto)                                             [KHG_K3_NY] */
 #define KHG_OPT_DEBUG 14         /* 1: planning statistics to stderr                                              [KHG_DEBUG] */
 #define KHG_OPT_K3_PHASE_A 15    /* per-Gaussian log-likelihoods of K3's wave form: 0 on the fp16 matrix cores in K1's f16x2s arithmetic where the model-derived scales hold, 1 the fp32 MFMA chain [KHG_K3_PHASEA=f32] */
-#define KHG_OPT_COUNT 16
+#define KHG_OPT_K2_SPLIT 16      /* an asynchronous khg_align (no host outputs) on a set of > 64 utterances lets the order-faithful decoders write to a
+                                    second alignment buffer, so that khg_acc_stats can accumulate the certified utterances while they still
+                                    run and add the others in a second pass: 0 (DEFAULT) on, 1 off                       [KHG_K2_SPLIT=off] */
+#define KHG_OPT_COUNT 17
 /* Read-only figures (khg_ctx_get_option only): the per-call scratch block behind small utterance sets (DESIGN.md "per-utterance calls"). */
 #define KHG_INFO_SCRATCH_BYTES 100   /* bytes of the block in use (its top), 0 before the first small set */
 #define KHG_INFO_SCRATCH_BLOCKS 101  /* live allocations inside it */

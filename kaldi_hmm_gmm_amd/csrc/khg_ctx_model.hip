@@ -168,7 +168,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 3}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 3}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
@@ -197,7 +197,8 @@ static void ctx_defaults_from_env(khg_ctx* c) {
     {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},
     {"KHG_K3_BUCKET", KHG_OPT_K3_BUCKET, "sort=0,atomic=1,count=2"}, {"KHG_K3_FORM", KHG_OPT_K3_FORM, "auto=0,block=1,valu=2"},
     {"KHG_K3_VALU", KHG_OPT_K3_FORM, "1=2"}, {"KHG_K3_PHASEB", KHG_OPT_K3_PHASE_B, "f64=0,f32=1,f16=2"},
-    {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}, {"KHG_K3_PHASEA", KHG_OPT_K3_PHASE_A, "auto=0,f16=0,f32=1"}};
+    {"KHG_K3_NY", KHG_OPT_K3_NY, ""}, {"KHG_DEBUG", KHG_OPT_DEBUG, ""}, {"KHG_K3_PHASEA", KHG_OPT_K3_PHASE_A, "auto=0,f16=0,f32=1"},
+    {"KHG_K2_SPLIT", KHG_OPT_K2_SPLIT, "on=0,off=1"}};
   c->opt[KHG_OPT_K1_INTERLEAVE] = -1;
   c->opt[KHG_OPT_K1P_TS] = 1024;
   c->opt[KHG_OPT_K3_PHASE_B] = 2;        // both phases of K3's wave form on the fp16 matrix cores where they apply (else the fp64 pipe)

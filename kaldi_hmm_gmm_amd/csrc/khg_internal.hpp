@@ -273,6 +273,12 @@ struct khg_utts {
   char* out_blk_d = nullptr; size_t out_blk_bytes = 0;   // small sets: [status | like | num_words | words | ali] in one arena block = one download
   hipEvent_t ev_dp = nullptr, ev_ali = nullptr;   // K2-DP done (main) -> faithful kernel (side) -> alignment complete
   bool ali_pending = false;
+  // split mode of khg_align (KHG_OPT_K2_SPLIT): the order-faithful decoders' alignments land in ali2_d; unc_d flags the utterances the
+  // DP left to them, unc_cnt_h (pinned, device-visible) counts them and their frames.  ali_split: ali2_d has not been merged into
+  // ali_d yet (wait_ali does it; khg_acc_stats first accumulates the certified utterances).
+  int32_t *ali2_d = nullptr, *unc_d = nullptr, *unc_cnt_h = nullptr, *unc_cnt_dev = nullptr;
+  int64_t* sub_off_d = nullptr;     // [U + 1] first position of an uncertified utterance's frames in the second K3 pass
+  bool ali_split = false;
   // K3 scratch
   int32_t *pdf_count_d = nullptr, *pdf_cursor_d = nullptr, *frame_ids_d = nullptr;
   uint32_t *sort_keys_d = nullptr, *sort_keys_out_d = nullptr, *sort_vals_d = nullptr; void* sort_tmp_d = nullptr; size_t sort_tmp_bytes = 0;

@@ -70,7 +70,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   a.ll = u->ll_d; a.ll_off = u->ll_off_d;
   a.bp = u->bp_d; a.bp_off = u->bp_off_d; a.layer_best = u->layer_best_d; a.layer_cnt = u->layer_cnt_d;
   a.path = u->path_d; a.path_off = u->path_off_d;
-  a.ali = u->ali_d; a.words = u->words_d; a.words_off = u->words_off_d; a.num_words = u->num_words_d;
+  a.ali = u->ali_d; a.ali_fb = u->ali_d; a.unc = nullptr; a.unc_cnt = nullptr; a.words = u->words_d; a.words_off = u->words_off_d; a.num_words = u->num_words_d;
   a.like = u->like_d; a.status = u->status_d; a.err_flag = ctx->err_flag_d;
   a.prof = nullptr;
   // launch order of the DP kernel: longest utterances first (built once per set)
@@ -85,8 +85,24 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
     if (rc2) return rc2;
   }
   a.order = ctx->opt[KHG_OPT_K2_INORDER] ? nullptr : u->k2_order_d;
+  // Split mode: nobody waits for the results here and the set is large -- the order-faithful decoders (side stream) write to ali2_d, the DP
+  // kernel leaves an uncertified utterance's range of ali_d zero, flags and counts it: khg_acc_stats can then accumulate the certified
+  // utterances while those decoders still run (khg_k3.hip); wait_ali merges.
+  const bool split = !(ali_h || like_h || status_h || words_h) && u->n_utt > 64 && !u->small && ctx->opt[KHG_OPT_K2_SPLIT] == 0;
+  if (split) {
+    if (!u->ali2_d) {
+      rc = u_alloc(u, &u->ali2_d, (size_t)u->N);
+      if (!rc) rc = u_alloc(u, &u->unc_d, (size_t)u->n_utt);
+      if (rc) return rc;
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&u->unc_cnt_h), 64, hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&u->unc_cnt_dev), u->unc_cnt_h, 0));
+    }
+    HIPCHK(hipMemsetAsync(u->unc_d, 0, sizeof(int32_t) * (size_t)u->n_utt, ctx->stream));
+    HIPCHK(hipMemsetAsync(u->unc_cnt_dev, 0, 2 * sizeof(int32_t), ctx->stream));
+    a.ali_fb = u->ali2_d; a.unc = u->unc_d; a.unc_cnt = u->unc_cnt_dev;
+  }
   const bool k2prof = ctx->opt[KHG_OPT_K2_PROF] != 0;
-  if (k2prof) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&a.prof), sizeof(long long) * 8 * (size_t)u->n_utt)); HIPCHK(hipMemset(a.prof, 0, sizeof(long long) * 8 * (size_t)u->n_utt)); }
+  if (k2prof) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&a.prof), sizeof(long long) * 16 * (size_t)u->n_utt)); HIPCHK(hipMemset(a.prof, 0, sizeof(long long) * 16 * (size_t)u->n_utt)); }   // [U][8] DP stamps | [U][8] chain-decoder stamps
   a.beam = cfg->beam; a.retry_beam = cfg->retry_beam; a.acoustic_scale = cfg->acoustic_scale;
   a.like_scale = cfg->like_scale != 0.0f ? cfg->like_scale : cfg->acoustic_scale;
   a.beam_delta = cfg->beam_delta; a.hash_ratio = cfg->hash_ratio;
@@ -128,7 +144,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const size_t S4 = (S + 3) & ~size_t(3);
   // token costs x 2 + state keys (24) | token states x 2 (8) | first / winner (8) | GetCutoff array (4) | in-arc offsets (4): 48 per state;
   // per out-arc slot: parked cost (8) + record (8) + info (4) + ordinal (1); score row; in-arc tables (12 + 2 per arc)
-  const size_t lds_chain = 48 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf + 14 * A + 128;
+  const size_t lds_chain = 48 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf + 14 * A + 33 * ((S + 15) & ~size_t(15)) + 128;    // ... + the trace-back's 33 staged rows
   const bool chain = fmode == 0 && !u->has_eps && S <= 1000 && u->max_outdeg <= 4 && lds_chain <= 64 * 1024 && max_npdf <= 32767;
   const bool wave_lds = (fmode == 0 || fmode == 3) && S <= 65535 && lds_w_mut + lds_w_graph <= 160 * 1024;
   const bool wave_gm = fmode != 1 && !wave_lds && S <= 65535 && lds_w_mut <= 160 * 1024;
@@ -228,16 +244,23 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   }
   HIPCHK(hipGetLastError());
   if (!sync_call) { HIPCHK(hipEventRecord(u->ev_ali, side)); u->ali_pending = true; }
+  u->ali_split = split;
   u->ali_valid = true;
   if (k2prof) {  // diagnostics: average s_memtime ticks per phase of k2_viterbi_dp
-    std::vector<long long> pr(8 * (size_t)u->n_utt);
+    std::vector<long long> pr(16 * (size_t)u->n_utt);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(side));
     HIPCHK(hipMemcpy(pr.data(), a.prof, pr.size() * 8, hipMemcpyDeviceToHost));
     (void)hipFree(a.prof);
     double ph[4] = {0, 0, 0, 0}, sT = 0, sS = 0, sf = 0; int n = 0;
     for (int i = 0; i < u->n_utt; ++i) if (pr[i * 8 + 4]) { for (int k = 0; k < 4; ++k) ph[k] += (double)(pr[i * 8 + k + 1] - pr[i * 8 + k]); sT += pr[i * 8 + 5]; sS += pr[i * 8 + 6]; sf += pr[i * 8 + 7]; ++n; }
     if (n) fprintf(stderr, "[KHG_K2_PROF] %d utts, avg T %.1f S %.1f fast %.2f threads %d lds %zu | ticks: setup %.0f forward %.0f traceback %.0f replay %.0f\n",
                    n, sT / n, sS / n, sf / n, nthr, lds_dp, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+    const long long* pc = pr.data() + 8 * (size_t)u->n_utt;     // chain decoder: 0 start, 1 set-up done, 2 frames done (all attempts), 3 finished, 4 frames decoded
+    double cs[3] = {0, 0, 0}, cf = 0, cp[3] = {0, 0, 0}; int nc = 0;
+    for (int i = 0; i < u->n_utt; ++i) if (pc[i * 8 + 3]) { for (int k = 0; k < 3; ++k) { cs[k] += (double)(pc[i * 8 + k + 1] - pc[i * 8 + k]); cp[k] += (double)pc[i * 8 + 5 + k]; } cf += (double)pc[i * 8 + 4]; ++nc; }
+    if (nc) fprintf(stderr, "[KHG_K2_PROF] chain decoder: %d utts, avg frames decoded %.1f | ticks: setup %.0f frames %.0f (%.1f per frame: GetCutoff %.1f, pass 1 %.1f, pass 2 %.1f, rest = row flush + score staging) finish %.0f\n",
+                    nc, cf / nc, cs[0] / nc, cs[1] / nc, cs[1] / std::max(1.0, cf), cp[0] / std::max(1.0, cf), cp[1] / std::max(1.0, cf), cp[2] / std::max(1.0, cf), cs[2] / nc);
   }
   if (!ali_h && !like_h && !status_h && !words_h) return KHG_OK;   // asynchronous: errors surface at khg_ctx_sync / downloads
   rc = wait_ali(ctx, u);

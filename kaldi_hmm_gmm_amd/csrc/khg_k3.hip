@@ -100,31 +100,16 @@ static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use)
   return KHG_OK;
 }
 
-static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
-  if (ctx_dead(ctx) || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
-  { int rf = utts_foreign_ctx(ctx, u, "khg_acc_stats"); if (rf) return rf; }
-  if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
-  if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
-    return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");
-  if (tm->max_pdf >= m->P) return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: transition model refers to pdf-ids the model does not have");
-  int rc = wait_ali(ctx, u);
-  if (!rc) rc = arena_flush(ctx);
-  if (rc) return rc;
-  if (!u->frame_ids_d || u->k3_P != m->P || u->k3_tids != tm->num_tids) {
-    DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d); DEVFREE(u->frame_ids_d);
-    rc = u_alloc(u, &u->pdf_count_d, (size_t)m->P);
-    if (!rc) rc = u_alloc(u, &u->pdf_cursor_d, (size_t)m->P);
-    if (!rc) rc = u_alloc(u, &u->pdf_start_d, (size_t)m->P + 1);
-    if (!rc) rc = u_alloc(u, &u->tid_count_d, (size_t)tm->num_tids + 1);
-    if (!rc) rc = u_alloc(u, &u->frame_ids_d, (size_t)u->N);
-    if (rc) return rc;
-    u->k3_P = m->P; u->k3_tids = tm->num_tids;
-  }
+// One pass of K3 over the set's resident alignment: all N frames (nsub < 0), or -- the second pass of the split mode -- the nsub frames
+// of the utterances the DP left to the order-faithful decoders (flagged in u->unc_d; their alignments are merged into ali_d by now).
+static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts, int64_t nsub) {
+  int rc = KHG_OK;
+  const int64_t Neff = nsub < 0 ? u->N : nsub;
   HIPCHK(hipMemsetAsync(u->pdf_count_d, 0, sizeof(int32_t) * (size_t)m->P, ctx->stream));
   HIPCHK(hipMemsetAsync(u->tid_count_d, 0, sizeof(unsigned long long) * ((size_t)tm->num_tids + 1), ctx->stream));
   K3Args a;
   a.feats = u->feats_d; a.ali = u->ali_d; a.id2pdf = tm->id2pdf_d; a.num_tids = tm->num_tids;
-  a.N = u->N; a.P = m->P; a.D = m->D;
+  a.N = Neff; a.P = m->P; a.D = m->D;
   a.gauss_off = m->gauss_off_d; a.gconsts = m->gconsts_d; a.means_invvars = m->miv_d; a.inv_vars = m->iv_d; a.nhalf_inv_vars = m->nhiv_d;
   a.pdf_count = u->pdf_count_d; a.pdf_start = u->pdf_start_d; a.pdf_cursor = u->pdf_cursor_d;
   a.frame_ids = u->frame_ids_d; a.tid_count = u->tid_count_d;
@@ -133,16 +118,16 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
   a.pa_ex = nullptr; a.pa_S = 0; a.pa_scale = 1.0f; a.pa_inv = 1.0f; a.pa_c1 = 1.44269504088896340736f;
   nparts = std::max(1, std::min(nparts, m->P));
   if (comm && nparts > 1) { rc = ctx_comm_stream(ctx); if (rc) return rc; }
-  if (u->N > 0) {
-    const int gb = (int)std::min<int64_t>(4096, (u->N + 255) / 256);
+  if (Neff > 0) {
+    const int gb = (int)std::min<int64_t>(4096, (Neff + 255) / 256);
     {
       KernelTimer kt(ctx, "k3_bucket");
       // KHG_OPT_K3_BUCKET = 1: cursor-bump scatter (bucket order depends on the atomics)
-      if (ctx->opt[KHG_OPT_K3_BUCKET] == 1 || u->N >= (int64_t)INT_MAX) {
+      if (nsub < 0 && (ctx->opt[KHG_OPT_K3_BUCKET] == 1 || u->N >= (int64_t)INT_MAX)) {
         KHG_LAUNCH(ctx, k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
         KHG_LAUNCH(ctx, k3_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
         KHG_LAUNCH(ctx, k3_scatter, dim3(gb), dim3(256), 0, ctx->stream, a);
-      } else if (ctx->opt[KHG_OPT_K3_BUCKET] == 2 && m->P <= K3_CS_MAXP) {
+      } else if (nsub < 0 && ctx->opt[KHG_OPT_K3_BUCKET] == 2 && m->P <= K3_CS_MAXP) {
         // the library's own stable counting sort (khg_k3_accstats.hip.inc: k3_cs_*; opt-in: 1.27 ms against the radix sort's 0.80 at the
         // bench size): blocks of CB consecutive frames
         const int nw = m->P + 1 <= 7168 ? 4 : 2;                      // waves of a placing block: nw x (P + 1 + 1024) counters of LDS
@@ -179,16 +164,21 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         }
         size_t need = 0;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
-                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)Neff, 0, bits, ctx->stream));
         if (need > u->sort_tmp_bytes) {
           DEVFREE(u->sort_tmp_d);
           { int rt = u_alloc(u, reinterpret_cast<char**>(&u->sort_tmp_d), need); if (rt) return rt; }
           u->sort_tmp_bytes = need;
         }
-        if (tm->num_tids <= K3_LDS_TIDS) KHG_LAUNCH(ctx, k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
+        if (nsub >= 0) {
+          // the (pdf, frame) pairs of the flagged utterances only, utterances in order: positions from an exclusive sum of their lengths
+          if (!u->sub_off_d) { rc = u_alloc(u, &u->sub_off_d, (size_t)u->n_utt + 1); if (rc) return rc; }
+          KHG_LAUNCH(ctx, k3_sub_scan, dim3(1), dim3(1024), 0, ctx->stream, u->unc_d, u->frame_off_d, u->n_utt, u->sub_off_d);
+          KHG_LAUNCH(ctx, k3_sub_keys, dim3((unsigned)std::min(u->n_utt, 8192)), dim3(64), 0, ctx->stream, a, u->unc_d, u->frame_off_d, u->sub_off_d, u->n_utt, u->sort_keys_d, u->sort_vals_d);
+        } else if (tm->num_tids <= K3_LDS_TIDS) KHG_LAUNCH(ctx, k3_sort_keys<true>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
         else KHG_LAUNCH(ctx, k3_sort_keys<false>, dim3(std::min(gb, 1024)), dim3(256), 0, ctx->stream, a, u->sort_keys_d, u->sort_vals_d);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(u->sort_tmp_d, need, u->sort_keys_d, u->sort_keys_out_d, u->sort_vals_d,
-                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)u->N, 0, bits, ctx->stream));
+                                                  reinterpret_cast<uint32_t*>(u->frame_ids_d), (int)Neff, 0, bits, ctx->stream));
         KHG_LAUNCH(ctx, k3_bounds, dim3((m->P + 256) / 256), dim3(256), 0, ctx->stream, a, u->sort_keys_out_d);
       }
     }
@@ -197,9 +187,9 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     // from N and P alone: the bucket sizes stay on the device) in *extra_blocks; parked: the slices park images (wave forms).
     int64_t k3_extra_blocks = 0;
     auto make_items = [&](int ny_base, bool parked, size_t nsum1) -> int {
-      const int64_t avg = u->N / std::max(1, m->P);
+      const int64_t avg = Neff / std::max(1, m->P);
       const int target = (int)std::min<int64_t>(1 << 30, std::max<int64_t>(512, 2 * avg / ny_base));
-      const int64_t per_t = u->N / target;
+      const int64_t per_t = Neff / target;
       k3_extra_blocks = std::min<int64_t>(per_t + m->P, 2 * per_t) + 1;
       const int64_t max_items = (int64_t)m->P * ny_base + k3_extra_blocks;
       const int64_t max_slots = !parked ? INT_MAX : ny_base > 1 ? max_items : 2 * per_t + 1;
@@ -228,7 +218,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     };
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
-    const int64_t avg_chunks = (u->N / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
+    const int64_t avg_chunks = (Neff / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
     const int k3form = ctx->opt[KHG_OPT_K3_FORM];     // 1: the chunk-per-block MFMA form for every shape; 2: the VALU form
     // the chunk-per-block MFMA form holds 16 * 4 * NBW Gaussians: NBW <= 2 at D <= 80, <= 4 at D <= 40 (the accumulators are registers)
     const bool use_mfma = (maxG <= 128 || (maxG <= 256 && m->KQ == 10)) && k3form != 2 && m->KQ != 0;
@@ -253,7 +243,7 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       const size_t lds = std::max<size_t>(f16a ? sizeof(float) * (4 * 4 * 16 * 20) + 2 * (size_t)(4 * 2 * 16 * K3_XH_ROW)
                                                : sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 4 * 16 * 20),
                                           sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
-      const int64_t avg_tiles = (u->N / std::max(1, m->P) + 15) / 16;
+      const int64_t avg_tiles = (Neff / std::max(1, m->P) + 15) / 16;
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, (avg_tiles + 15) / 16), (4096 + m->P - 1) / m->P));
       if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
       // per-pdf log-like partials (always) and, with several blocks per pdf, the slice images they park
@@ -372,6 +362,43 @@ static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     if (rc) return rc;
   }
   return KHG_OK;   // asynchronous: kernel-side errors surface at khg_ctx_sync / khg_accs_download
+}
+static int acc_stats_impl(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc, void* comm, int nparts) {
+  if (ctx_dead(ctx) || !m || !tm || !u || !acc) return khg_set_error(KHG_E_ARG, "khg_acc_stats: bad arguments");
+  { int rf = utts_foreign_ctx(ctx, u, "khg_acc_stats"); if (rf) return rf; }
+  if (!u->ali_valid) return khg_set_error(KHG_E_ARG, "khg_acc_stats: no resident alignment (khg_align or khg_ali_upload first)");
+  if (m->D != u->D || acc->D != m->D || acc->sumG != m->sumG || acc->num_tids != tm->num_tids)
+    return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: accumulator / model / feature dimensions do not match");
+  if (tm->max_pdf >= m->P) return khg_set_error(KHG_E_RUNTIME, "khg_acc_stats: transition model refers to pdf-ids the model does not have");
+  // Split mode (khg_k2.hip): the order-faithful decoders may still be running on their side stream, writing to their own buffer.  The DP
+  // kernel counted what it left to them: wait for IT (the host joins the stream once, right behind K2), and if there is anything,
+  // accumulate the certified utterances now -- their ranges of ali_d are final, the others' are zero -- and the rest in a second pass
+  // once the decoders are done.  Statistics are additive (csrc/mle-am-diag-gmm.cc:41-52); the second pass is the same kernels over
+  // the flagged utterances' frames.
+  int64_t nsub = -1;
+  if (u->ali_pending && u->ali_split && u->N > 0) {
+    HIPCHK(hipEventSynchronize(u->ev_dp));
+    if (u->unc_cnt_h[0] == 0) u->ali_split = false;         // nothing to merge, nothing to wait for but the (empty) side stream
+    else nsub = u->unc_cnt_h[1];
+  }
+  int rc = nsub < 0 ? wait_ali(ctx, u) : KHG_OK;
+  if (!rc) rc = arena_flush(ctx);
+  if (rc) return rc;
+  if (!u->frame_ids_d || u->k3_P != m->P || u->k3_tids != tm->num_tids) {
+    DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d); DEVFREE(u->frame_ids_d);
+    rc = u_alloc(u, &u->pdf_count_d, (size_t)m->P);
+    if (!rc) rc = u_alloc(u, &u->pdf_cursor_d, (size_t)m->P);
+    if (!rc) rc = u_alloc(u, &u->pdf_start_d, (size_t)m->P + 1);
+    if (!rc) rc = u_alloc(u, &u->tid_count_d, (size_t)tm->num_tids + 1);
+    if (!rc) rc = u_alloc(u, &u->frame_ids_d, (size_t)u->N);
+    if (rc) return rc;
+    u->k3_P = m->P; u->k3_tids = tm->num_tids;
+  }
+  if (nsub < 0) return acc_stats_pass(ctx, m, tm, u, weight, acc, comm, nparts, -1);
+  rc = acc_stats_pass(ctx, m, tm, u, weight, acc, nullptr, 1, -1);          // the exchange (if any) follows the second pass
+  if (!rc) rc = wait_ali(ctx, u);                                             // decoders done -> their alignments merged into ali_d
+  if (!rc) rc = acc_stats_pass(ctx, m, tm, u, weight, acc, comm, nparts, nsub);
+  return rc;
 }
 extern "C" int khg_acc_stats(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, khg_utts* u, float weight, khg_accs* acc) {
   return acc_stats_impl(ctx, m, tm, u, weight, acc, nullptr, 1);

@@ -75,7 +75,7 @@ struct KContext {
   static int opt_id(const py::object& o) {
     if (py::isinstance<py::int_>(o)) return o.cast<int>();
     static const char* names[KHG_OPT_COUNT] = {"k1_form", "k1_order", "k1_nf", "k1p_ts", "k1_interleave", "k1_dbg", "k2_inorder", "k2_ks", "k2_serial",
-                                               "k2_prof", "k3_bucket", "k3_form", "k3_phase_b", "k3_ny", "debug", "k3_phase_a"};
+                                               "k2_prof", "k3_bucket", "k3_form", "k3_phase_b", "k3_ny", "debug", "k3_phase_a", "k2_split"};
     const std::string n = o.cast<std::string>();
     for (int i = 0; i < KHG_OPT_COUNT; ++i) if (n == names[i]) return i;
     if (n == "scratch_bytes") return KHG_INFO_SCRATCH_BYTES;       // read-only

@@ -280,6 +280,8 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d); DEVFREE(u->xh_d); DEVFREE(u->xh_ex_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
   DEVFREE(u->xs_d); DEVFREE(u->xs_ex_d); DEVFREE(u->schunks_d); DEVFREE(u->sunits_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
+  DEVFREE(u->ali2_d); DEVFREE(u->unc_d); DEVFREE(u->sub_off_d);
+  if (u->unc_cnt_h) { (void)hipHostFree(u->unc_cnt_h); u->unc_cnt_h = nullptr; }
   DEVFREE(u->layer_best_d); DEVFREE(u->layer_cnt_d); DEVFREE(u->path_d); DEVFREE(u->k2_gscratch_d); DEVFREE(u->k2_order_d);
   DEVFREE(u->ali_d); DEVFREE(u->words_d); DEVFREE(u->num_words_d); DEVFREE(u->status_d); DEVFREE(u->like_d);
   DEVFREE(u->pdf_count_d); DEVFREE(u->pdf_cursor_d); DEVFREE(u->frame_ids_d); DEVFREE(u->pdf_start_d); DEVFREE(u->tid_count_d);
@@ -303,7 +305,21 @@ extern "C" int khg_utts_pdfs(const khg_utts* u, int32_t* pdfs) {
 }
 
 // the main stream must not touch ali / status / the ll buffer while the side-stream decoder runs
+// split mode: the alignments the order-faithful decoders wrote to their own buffer go into the set's alignment
+__global__ void k2_merge_fallback(const int32_t* __restrict__ unc, const int64_t* __restrict__ frame_off, const int32_t* __restrict__ ali2,
+                                  int32_t* __restrict__ ali, int n_utt) {
+  for (int u = blockIdx.x; u < n_utt; u += gridDim.x) {
+    if (!unc[u]) continue;
+    const int64_t f0 = frame_off[u], f1 = frame_off[u + 1];
+    for (int64_t f = f0 + threadIdx.x; f < f1; f += blockDim.x) ali[f] = ali2[f];
+  }
+}
 int wait_ali(khg_ctx* ctx, khg_utts* u) {
   if (u->ali_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, u->ev_ali, 0)); u->ali_pending = false; }
+  if (u->ali_split) {
+    u->ali_split = false;
+    KHG_LAUNCH(ctx, k2_merge_fallback, dim3((unsigned)std::min(u->n_utt, 16384)), dim3(64), 0, ctx->stream, u->unc_d, u->frame_off_d, u->ali2_d, u->ali_d, u->n_utt);
+    HIPCHK(hipGetLastError());
+  }
   return KHG_OK;
 }

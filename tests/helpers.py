@@ -75,7 +75,7 @@ def token_path_cost(graphs, u, ali, ll_u, pdf_list, cost, id2pdf, acoustic_scale
     return True, float(np.add.accumulate(terms)[-1] + np.float64(fin))
 
 
-def oracle_replay(m, gc, ut, cost, n_utt, acoustic_scale=0.1, beam=200.0, retry_beam=0.0, threads=None):
+def oracle_replay(m, gc, ut, cost, n_utt, acoustic_scale=0.1, beam=200.0, retry_beam=0.0, threads=None, **kw):
     """The oracle's own answer for the first `n_utt` utterances of a set, computed utterance-parallel inside the C oracle
     (orc_em_pass_mt_keep: orc_align_utterance + orc_acc_stats_ali per utterance, the calls the one-thread path makes): alignments,
     status, like and the accumulators of those utterances.  ~30 k frames/s per core at 5000 x 64 x 40."""
@@ -87,7 +87,7 @@ def oracle_replay(m, gc, ut, cost, n_utt, acoustic_scale=0.1, beam=200.0, retry_
     keep = {}
     nthr = threads or max(1, min(len(os.sched_getaffinity(0)), 16))
     fr, nn, failed, _ = orc.em_pass_mt(om, m.id2pdf, g, ut.frame_off, ut.feats, first_utt=0, n_utt=n_utt, num_threads=nthr,
-                                       acoustic_scale=acoustic_scale, beam=beam, retry_beam=retry_beam, keep=keep)
+                                       acoustic_scale=acoustic_scale, beam=beam, retry_beam=retry_beam, keep=keep, **kw)
     assert nn == n_utt
     keep["n_utt"], keep["frames"] = n_utt, int(ut.frame_off[n_utt])
     return keep

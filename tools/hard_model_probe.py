@@ -34,4 +34,8 @@ for ms in scales:
         same = float((res["ali"] == ut.ref_ali).mean())
         print(f"mismatch {ms}: beam {beam}/{retry}: {dt*1e3:.1f} ms for {U} utts  exact_dp={(st & 4 > 0).sum()} fallback={(st & 8 > 0).sum()} retried={(st & 2 > 0).sum()} error={(st & 1).sum()} frames=generating path {same:.3f}  kernels " +
               ", ".join(f"{k} {v:.2f}" for k, v in km.items() if k.startswith("k2")), flush=True)
+    if len(sys.argv) > 3:      # per-phase cycle stamps of the DP and the chain decoder (stderr)
+        ctx.set_option("k2_prof", 1)
+        us.align(tm, beam=6, retry_beam=40, acoustic_scale=0.1); ctx.sync()
+        ctx.set_option("k2_prof", 0)
     us.close(); tm.close(); dm.close()
