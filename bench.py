@@ -840,55 +840,85 @@ def main():
     # the recipe's own beams (egs/yesno/train.py:165-167: beam 6, retry 40) on the same set: no band (a narrow beam fails many
     # certificates: khg_loglikes_reachable), two timed steps, then who was retried / went through the order-faithful decoder
     recipe_line = None
+    flat_line = None
     if not args.no_recipe_beam_line and args.beam != 6.0:
-        def step_recipe(download=False):
-            accs.zero()
-            dm.invalidate()
-            st_all = []
-            for s_ in sets:
-                s_.loglikes(dm, reachable_only=True, band=False)
-                r_ = s_.align(tm, beam=6.0, retry_beam=40.0, acoustic_scale=0.1, download="summary" if download else False)
-                if download:
-                    st_all.append(np.asarray(r_["status"]))
-            for s_ in sets:
-                s_.acc_stats(dm, tm, accs)
-            return st_all
-        step_recipe()
-        torch.cuda.synchronize()
-        for c in ctxs:
-            c.sync(); c.set_timing(True)
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
+        def recipe_steps(dmodel):
+            """Two timed steps at beam 6 / retry 40 with `dmodel` -> (seconds, kernel ms, [retried, fallback, failed] utterances over all ranks)."""
+            def step_recipe(download=False):
+                accs.zero()
+                dmodel.invalidate()
+                st_all = []
+                for s_ in sets:
+                    s_.loglikes(dmodel, reachable_only=True, band=False)
+                    r_ = s_.align(tm, beam=6.0, retry_beam=40.0, acoustic_scale=0.1, download="summary" if download else False)
+                    if download:
+                        st_all.append(np.asarray(r_["status"]))
+                for s_ in sets:
+                    s_.acc_stats(dmodel, tm, accs)
+                return st_all
             step_recipe()
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        dtr = time.perf_counter() - t0
-        kr = {}
-        for c in ctxs:
-            for name, ms in c.timings():
-                kr[name] = kr.get(name, 0.0) + ms
-            c.set_timing(False)
-        st = np.concatenate(step_recipe(download=True)) if n_local else np.zeros(0, np.int32)
-        torch.cuda.synchronize()
-        cnt = torch.tensor([dtr, float(((st & 2) != 0).sum()), float(((st & 8) != 0).sum()), float(((st & 1) != 0).sum())],
-                           device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        if dist_on:
-            mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-            dtr = float(mx[0])
+            torch.cuda.synchronize()
+            for c in ctxs:
+                c.sync(); c.set_timing(True)
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step_recipe()
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            dtr = time.perf_counter() - t0
+            kr = {}
+            for c in ctxs:
+                for name, ms in c.timings():
+                    kr[name] = kr.get(name, 0.0) + ms
+                c.set_timing(False)
+            st = np.concatenate(step_recipe(download=True)) if n_local else np.zeros(0, np.int32)
+            torch.cuda.synchronize()
+            cnt = torch.tensor([dtr, float(((st & 2) != 0).sum()), float(((st & 8) != 0).sum()), float(((st & 1) != 0).sum())],
+                               device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            if dist_on:
+                mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+                dtr = float(mx[0])
+            return dtr, {k: v / 2 for k, v in sorted(kr.items())}, [int(cnt[1]), int(cnt[2]), int(cnt[3])]
+
+        dtr, kr, cnt = recipe_steps(dm)
         recipe_line = {"beam": 6.0, "retry_beam": 40.0, "k1_cells": "khg_loglikes_reachable (no band)", "steps": 2, "ms_per_step": dtr / 2 * 1e3,
-                       "value": frames_total * 2 / dtr, "kernel_ms_per_step": {k: v / 2 for k, v in sorted(kr.items())},
-                       "retried_utts": int(cnt[1]), "fallback_decoder_utts": int(cnt[2]), "failed_utts": int(cnt[3]), "utterances": args.utts,
+                       "value": frames_total * 2 / dtr, "kernel_ms_per_step": kr,
+                       "retried_utts": cnt[0], "fallback_decoder_utts": cnt[1], "failed_utts": cnt[2], "utterances": args.utts,
                        "note": "the recipe's AlignConfig (egs/yesno/train.py:165-167) on the benchmark's set: retried = num_retried of "
                                "decoder-wrappers.cc:68-75, fallback = utterances whose exact-DP beam certificate failed and that the order-"
                                "faithful FasterDecoder kernel decoded; with the TRAINED-like synthetic model of this set (Gaussians ~27 sigma "
                                "apart) the correct path wins by a wide margin, so few utterances leave the certified path -- "
-                               "tools/fallback_stress.py is the flat-start-like case (~45 % through the fallback)"}
+                               "flat_start_line is the other regime"}
+        # The regime of a recipe's EARLY realign passes (egs/yesno/train.py:165-202 right after the flat start): the same set scored with a
+        # MISMATCHED model (a tenth of the pdfs traded parameters: sure of itself and wrong there, synth.mismatched_model), beam 6 /
+        # retry 40.  The best path leaves the beam, the certificate fails and the order-faithful decoders (csrc/faster-decoder.cc:154-335)
+        # produce the answer for a large share of the utterances: their time is on this record, beside the headline's.
+        dm_flat = None
+        try:
+            mm = synth.mismatched_model(model, 0.1, seed=args.seed + 5)
+            gc_flat = np.zeros_like(gc)
+            _lib.check(_lib.lib.khg_compute_gconsts(mm.num_pdfs, D, _lib.ptr(mm.gauss_off, C.c_int32), _lib.ptr(mm.weights, C.c_float), _lib.ptr(mm.inv_vars, C.c_float),
+                                                    _lib.ptr(mm.means_invvars, C.c_float), _lib.ptr(gc_flat, C.c_float), None))
+            dm_flat = DeviceModel(ctxs[0], mm.gauss_off, gc_flat, mm.means_invvars, mm.inv_vars)
+            dtf, kf, cntf = recipe_steps(dm_flat)
+            k2f = kf.get("k2_viterbi_dp", 0.0) + kf.get("k2_viterbi_faithful", 0.0)
+            flat_line = {"beam": 6.0, "retry_beam": 40.0, "scoring_model": "synth.mismatched_model(fraction 0.1): 10 % of the pdfs traded parameters", "steps": 2,
+                         "ms_per_step": dtf / 2 * 1e3, "value": frames_total * 2 / dtf, "kernel_ms_per_step": kf,
+                         "retried_utts": cntf[0], "fallback_decoder_utts": cntf[1], "failed_utts": cntf[2], "utterances": args.utts,
+                         "fallback_share": cntf[1] / max(args.utts, 1), "k2_ms_per_step": {"exact_dp": kf.get("k2_viterbi_dp"), "order_faithful": kf.get("k2_viterbi_faithful"), "sum": k2f},
+                         "note": "k2_viterbi_faithful runs on a side stream beside K3's first pass (the certified utterances); K3's kernels appear twice "
+                                 "per step in kernel_ms_per_step (second pass: the utterances the order-faithful decoders aligned)"}
+        except Exception as ex:       # (a side line must not cost the headline)
+            flat_line = {"error": repr(ex)}
+        finally:
+            if dm_flat is not None:
+                dm_flat.close()
 
-    if recipe_line is not None or fp32_line is not None:
+    if recipe_line is not None or fp32_line is not None or flat_line is not None:
         step()                                        # the block holds the headline configuration's sums (over all shards) again
         torch.cuda.synchronize()
         del ar_events[args.steps:]
@@ -1094,6 +1124,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["recipe_beam_line"] = recipe_line
+        out["flat_start_line"] = flat_line
         if args.per_call_utts > 0 and world == 1:
             out["per_call_line"] = per_call_line(args, model, ut, feats, D, ctxs[0], out.get("cpu_baseline"))
         record = json.dumps(out)

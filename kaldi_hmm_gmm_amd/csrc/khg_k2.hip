@@ -92,13 +92,12 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   if (split) {
     if (!u->ali2_d) {
       rc = u_alloc(u, &u->ali2_d, (size_t)u->N);
-      if (!rc) rc = u_alloc(u, &u->unc_d, (size_t)u->n_utt);
+      if (!rc) rc = u_alloc(u, &u->unc_d, (size_t)u->n_utt + 2);       // flags | [utterances, frames] the DP could not certify
       if (rc) return rc;
-      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&u->unc_cnt_h), 64, hipHostMallocMapped));
-      HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&u->unc_cnt_dev), u->unc_cnt_h, 0));
+      u->unc_cnt_dev = u->unc_d + u->n_utt;
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&u->unc_cnt_h), 64, 0));   // pinned landing place of the two counters
     }
-    HIPCHK(hipMemsetAsync(u->unc_d, 0, sizeof(int32_t) * (size_t)u->n_utt, ctx->stream));
-    HIPCHK(hipMemsetAsync(u->unc_cnt_dev, 0, 2 * sizeof(int32_t), ctx->stream));
+    HIPCHK(hipMemsetAsync(u->unc_d, 0, sizeof(int32_t) * ((size_t)u->n_utt + 2), ctx->stream));
     a.ali_fb = u->ali2_d; a.unc = u->unc_d; a.unc_cnt = u->unc_cnt_dev;
   }
   const bool k2prof = ctx->opt[KHG_OPT_K2_PROF] != 0;
@@ -143,8 +142,8 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   const int odeg_c = (int)std::max<int32_t>(1, u->max_outdeg);
   const size_t S4 = (S + 3) & ~size_t(3);
   // token costs x 2 + state keys (24) | token states x 2 (8) | first / winner (8) | GetCutoff array (4) | in-arc offsets (4): 48 per state;
-  // per out-arc slot: parked cost (8) + record (8) + info (4) + ordinal (1); score row; in-arc tables (12 + 2 per arc)
-  const size_t lds_chain = 48 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf + 14 * A + 33 * ((S + 15) & ~size_t(15)) + 128;    // ... + the trace-back's 33 staged rows
+  // per out-arc slot: parked cost (8) + record (8) + info (4) + ordinal (1); score row; in-arc sources (2 per arc); the trace-back's 9 rows
+  const size_t lds_chain = 48 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf + 2 * A + 9 * ((S + 15) & ~size_t(15)) + 128;
   const bool chain = fmode == 0 && !u->has_eps && S <= 1000 && u->max_outdeg <= 4 && lds_chain <= 64 * 1024 && max_npdf <= 32767;
   const bool wave_lds = (fmode == 0 || fmode == 3) && S <= 65535 && lds_w_mut + lds_w_graph <= 160 * 1024;
   const bool wave_gm = fmode != 1 && !wave_lds && S <= 65535 && lds_w_mut <= 160 * 1024;
@@ -210,6 +209,7 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   hipStream_t side = ctx->stream;
   if (!sync_call) {
     if (!u->ev_dp) { HIPCHK(hipEventCreateWithFlags(&u->ev_dp, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&u->ev_ali, hipEventDisableTiming)); }
+    if (split) HIPCHK(hipMemcpyAsync(u->unc_cnt_h, u->unc_cnt_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));   // read by khg_acc_stats behind ev_dp
     HIPCHK(hipEventRecord(u->ev_dp, ctx->stream));
     side = ctx->sides[ctx->next_side];
     ctx->side_dirty[ctx->next_side] = true;

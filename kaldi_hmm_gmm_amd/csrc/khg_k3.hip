@@ -121,7 +121,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
   if (Neff > 0) {
     const int gb = (int)std::min<int64_t>(4096, (Neff + 255) / 256);
     {
-      KernelTimer kt(ctx, "k3_bucket");
+      KernelTimer kt(ctx, nsub < 0 ? "k3_bucket" : "k3_bucket_pass2");
       // KHG_OPT_K3_BUCKET = 1: cursor-bump scatter (bucket order depends on the atomics)
       if (nsub < 0 && (ctx->opt[KHG_OPT_K3_BUCKET] == 1 || u->N >= (int64_t)INT_MAX)) {
         KHG_LAUNCH(ctx, k3_count, dim3(gb), dim3(256), 0, ctx->stream, a);
@@ -264,7 +264,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       a.pdf0 = p0; a.npdf = np;
       const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
       {
-      KernelTimer kt(ctx, "k3_accumulate");
+      KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
       // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
       // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
       const bool exact_b = ctx->opt[KHG_OPT_K3_PHASE_B] != 1;       // (2 = the fp16 matrix cores where they apply, else fp64)
@@ -311,7 +311,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         a.pdf0 = p0; a.npdf = np;
         const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
-          KernelTimer kt(ctx, "k3_accumulate");
+          KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
           if (m->KQ == 10 && maxG <= 64) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
           else if (m->KQ == 10 && maxG <= 128) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
           else if (m->KQ == 10 && maxG <= 192) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 3>), dim3(nblk), dim3(256), lds, ctx->stream, a);
@@ -335,7 +335,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         a.pdf0 = p0; a.npdf = np;
         const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
-          KernelTimer kt(ctx, "k3_accumulate");
+          KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
           if (m->KQ == 10) KHG_LAUNCH(ctx, k3_accumulate<10>, dim3(nblk), dim3(256), lds, ctx->stream, a);
           else if (m->KQ == 20) KHG_LAUNCH(ctx, k3_accumulate<20>, dim3(nblk), dim3(256), lds, ctx->stream, a);
           else KHG_LAUNCH(ctx, k3_accumulate<0>, dim3(nblk), dim3(256), lds, ctx->stream, a);
