@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--per-call-utts", type=int, default=int(os.environ.get("KHG_BENCH_PERCALL_UTTS", "256")),
                     help="utterances pushed through gmm_align_compiled + gmm_acc_stats_ali ONE CALL EACH after the timed region (per_call_line); 0 = skip")
     ap.add_argument("--no-recipe-beam-line", action="store_true", help="skip the two extra steps at the recipe's beam 6 / retry 40 (recipe_beam_line)")
+    ap.add_argument("--flat-fraction", type=float, default=0.1,
+                    help="flat_start_line: share of the pdfs that trade parameters in the mismatched scoring model (synth.mismatched_model)")
     ap.add_argument("--c1-parts", type=int, default=4,
                     help="--allreduce khg: C1 pipelined behind K3 in this many pdf ranges (khg_acc_stats_reduce); 1 = one all-reduce of the "
                          "whole block behind K3 (khg_accs_allreduce)")
@@ -899,14 +901,14 @@ def main():
         # produce the answer for a large share of the utterances: their time is on this record, beside the headline's.
         dm_flat = None
         try:
-            mm = synth.mismatched_model(model, 0.1, seed=args.seed + 5)
+            mm = synth.mismatched_model(model, args.flat_fraction, seed=args.seed + 5)
             gc_flat = np.zeros_like(gc)
             _lib.check(_lib.lib.khg_compute_gconsts(mm.num_pdfs, D, _lib.ptr(mm.gauss_off, C.c_int32), _lib.ptr(mm.weights, C.c_float), _lib.ptr(mm.inv_vars, C.c_float),
                                                     _lib.ptr(mm.means_invvars, C.c_float), _lib.ptr(gc_flat, C.c_float), None))
             dm_flat = DeviceModel(ctxs[0], mm.gauss_off, gc_flat, mm.means_invvars, mm.inv_vars)
             dtf, kf, cntf = recipe_steps(dm_flat)
             k2f = kf.get("k2_viterbi_dp", 0.0) + kf.get("k2_viterbi_faithful", 0.0)
-            flat_line = {"beam": 6.0, "retry_beam": 40.0, "scoring_model": "synth.mismatched_model(fraction 0.1): 10 % of the pdfs traded parameters", "steps": 2,
+            flat_line = {"beam": 6.0, "retry_beam": 40.0, "scoring_model": "synth.mismatched_model(fraction %g): that share of the pdfs traded parameters" % args.flat_fraction, "steps": 2,
                          "ms_per_step": dtf / 2 * 1e3, "value": frames_total * 2 / dtf, "kernel_ms_per_step": kf,
                          "retried_utts": cntf[0], "fallback_decoder_utts": cntf[1], "failed_utts": cntf[2], "utterances": args.utts,
                          "fallback_share": cntf[1] / max(args.utts, 1), "k2_ms_per_step": {"exact_dp": kf.get("k2_viterbi_dp"), "order_faithful": kf.get("k2_viterbi_faithful"), "sum": k2f},

@@ -105,7 +105,7 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
 #define KHG_OPT_K2_PROF 9        /* 1: per-utterance cycle stamps of K2 to stderr                                 [KHG_K2_PROF] */
 #define KHG_OPT_K3_BUCKET 10     /* frames by pdf: 0 stable radix sort of (pdf, frame) pairs (rocPRIM; reproducible sums), 1 atomic cursor scatter, 2 the library's own stable counting sort (same order as 0, slower) [KHG_K3_BUCKET=sort|atomic|count] */
 #define KHG_OPT_K3_FORM 11       /* 0 auto, 1 the chunk-per-block MFMA form for every shape, 2 the VALU form      [KHG_K3_FORM=block, KHG_K3_VALU=1] */
-#define KHG_OPT_K3_PHASE_B 12    /* gamma . x: 0 on the fp64 matrix pipe (exact products), 1 fp32 pipe, 256-frame fp32 partial sums, 2 (DEFAULT) on the fp16 matrix cores (operands split into two fp16 pieces, 32-frame fp32 partial sums added in fp64; pdfs of 33..64 Gaussians, D <= 40, else as 0) [KHG_K3_PHASEB=f32|f16] */
+#define KHG_OPT_K3_PHASE_B 12    /* gamma . x: 0 on the fp64 matrix pipe (exact products), 1 as 0 (the fp32-pipe form of rounds 3-5 was removed in round 6), 2 (DEFAULT) on the fp16 matrix cores (operands split into two fp16 pieces, 32-frame fp32 partial sums added in fp64; pdfs of 33..64 Gaussians, D <= 40, else as 0) [KHG_K3_PHASEB=f32|f16] */
 #define KHG_OPT_K3_NY 13         /* workgroups per pdf in K3 (0 auto)                                             [KHG_K3_NY] */
 #define KHG_OPT_DEBUG 14         /* 1: planning statistics to stderr                                              [KHG_DEBUG] */
 #define KHG_OPT_K3_PHASE_A 15    /* per-Gaussian log-likelihoods of K3's wave form: 0 on the fp16 matrix cores in K1's f16x2s arithmetic where the model-derived scales hold, 1 the fp32 MFMA chain [KHG_K3_PHASEA=f32] */

@@ -186,22 +186,25 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     // average slice (2 x; silence in real transcripts).  -> the number of blocks to launch for a range of np pdfs (an upper bound
     // from N and P alone: the bucket sizes stay on the device) in *extra_blocks; parked: the slices park images (wave forms).
     int64_t k3_extra_blocks = 0;
-    auto make_items = [&](int ny_base, bool parked, size_t nsum1) -> int {
+    // Work items of one CLASS of pdfs (cls_lo < Gaussians <= cls_hi; the others get none): the form is chosen per pdf, so one pdf
+    // that Split (csrc/diag-gmm.cc:780-851) pushed past 64 Gaussians does not take every other pdf off the wave form.  Two classes
+    // keep their item lists side by side in the same buffers (second = true: the upper halves).
+    auto make_items = [&](int ny_base, bool parked, size_t nsum1, int cls_lo, int cls_hi, bool second) -> int {
       const int64_t avg = Neff / std::max(1, m->P);
       const int target = (int)std::min<int64_t>(1 << 30, std::max<int64_t>(512, 2 * avg / ny_base));
       const int64_t per_t = Neff / target;
       k3_extra_blocks = std::min<int64_t>(per_t + m->P, 2 * per_t) + 1;
       const int64_t max_items = (int64_t)m->P * ny_base + k3_extra_blocks;
       const int64_t max_slots = !parked ? INT_MAX : ny_base > 1 ? max_items : 2 * per_t + 1;
-      if (max_items >= INT_MAX) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: too many work items");
+      if (max_items >= INT_MAX / 2) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: too many work items");
       if (u->k3_items_n < (size_t)max_items) {
         DEVFREE(u->k3_items_d);
-        { int ri = u_alloc(u, reinterpret_cast<K3Item**>(&u->k3_items_d), (size_t)max_items); if (ri) return ri; }
+        { int ri = u_alloc(u, reinterpret_cast<K3Item**>(&u->k3_items_d), 2 * (size_t)max_items); if (ri) return ri; }
         u->k3_items_n = (size_t)max_items;
       }
       if (u->k3_item_off_n < (size_t)m->P + 1) {
         DEVFREE(u->k3_item_off_d);
-        int rc2 = u_alloc(u, &u->k3_item_off_d, (size_t)m->P + 1);
+        int rc2 = u_alloc(u, &u->k3_item_off_d, 2 * ((size_t)m->P + 1));
         if (rc2) return rc2;
         u->k3_item_off_n = (size_t)m->P + 1;
       }
@@ -211,20 +214,16 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         if (rc2) return rc2;
         u->k3_part_n = (size_t)max_slots * nsum1;
       }
+      K3Item* items = reinterpret_cast<K3Item*>(u->k3_items_d) + (second ? u->k3_items_n : 0);
+      int32_t* item_off = u->k3_item_off_d + (second ? u->k3_item_off_n : 0);
       KHG_LAUNCH(ctx, k3_make_items, dim3(1), dim3(1024), 0, ctx->stream, a, ny_base, target, (int)max_items, (int)std::min<int64_t>(max_slots, INT_MAX),
-                         reinterpret_cast<K3Item*>(u->k3_items_d), u->k3_item_off_d);
-      a.items = reinterpret_cast<const K3Item*>(u->k3_items_d); a.item_off = u->k3_item_off_d;
+                         items, item_off, cls_lo, cls_hi);
+      a.items = items; a.item_off = item_off;
       return KHG_OK;
     };
-    int maxG = 0;
-    for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);
-    const int64_t avg_chunks = (Neff / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
     const int k3form = ctx->opt[KHG_OPT_K3_FORM];     // 1: the chunk-per-block MFMA form for every shape; 2: the VALU form
-    // the chunk-per-block MFMA form holds 16 * 4 * NBW Gaussians: NBW <= 2 at D <= 80, <= 4 at D <= 40 (the accumulators are registers)
-    const bool use_mfma = (maxG <= 128 || (maxG <= 256 && m->KQ == 10)) && k3form != 2 && m->KQ != 0;
-    const bool use_wave = use_mfma && m->KQ == 10 && maxG <= 64 && k3form != 1;
-    if (use_wave) {
-      // wave-local form: W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards
+    // ---- the wave-local form (pdfs of <= 64 Gaussians at D <= 40): W in LDS + per-wave planes during the tile loop, the fp64 fold image afterwards ----
+    auto run_wave = [&](int cls_lo, int cls_hi, int maxG, void* comm_) -> int {
       const int nb = (maxG + 15) / 16;
       // phase A on the fp16 matrix cores where the model-derived scales hold (KHG_K3_PHASEA=f32 keeps the fp32 chain)
       bool f16a = false;
@@ -254,35 +253,31 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         if (rc) return rc;
         u->k3_llpart_n = (size_t)m->P;
       }
-      rc = make_items(ny, true, nsum1);
+      rc = make_items(ny, true, nsum1, cls_lo, cls_hi, false);
       if (rc) return rc;
       HIPCHK(hipMemsetAsync(u->k3_llpart_d, 0, sizeof(double) * (size_t)m->P, ctx->stream));
       a.ll_part = u->k3_llpart_d;
       a.part = u->k3_part_d;
-      for (int part = 0; part < nparts; ++part) {
-      const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      const int nparts_ = comm_ ? nparts : 1;
+      for (int part = 0; part < nparts_; ++part) {
+      const int p0 = (int)((int64_t)m->P * part / nparts_), np = (int)((int64_t)m->P * (part + 1) / nparts_) - p0;
       a.pdf0 = p0; a.npdf = np;
       const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
       {
       KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
-      // phase B on the fp64 matrix pipe (default: products exact, N ranks sum to the one-rank statistics to 1e-12) or, with
-      // KHG_K3_PHASEB=f32, on the fp32 pipe with 256-frame fp32 partial sums (k3_accumulate_wave32: 13 % faster, ~1e-6)
-      const bool exact_b = ctx->opt[KHG_OPT_K3_PHASE_B] != 1;       // (2 = the fp16 matrix cores where they apply, else fp64)
-      // k3_accumulate_wave32: the workgroup's fp64 image + W + two x planes per wave
-      const size_t lds32 = sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16) + sizeof(float) * ((size_t)nb * 20 * 64 + 4 * 2 * 16 * 20);
+      // phase B on the fp64 matrix pipe (products exact, N ranks sum to the one-rank statistics to 1e-12) or on the fp16 matrix
+      // cores (default where they apply)
+      const bool exact_b = true;
       // k3_accumulate_wave16: per wave two tiles' phase-A planes + the phase-B planes (halves), then the split W operands
       const size_t lds16 = std::max<size_t>(2 * (size_t)4 * (2 * (2 * 16 * K3_XH_ROW) + 2 * 2 * 40 * 36) + (size_t)nb * 3 * 2 * 64 * 16,
                                             sizeof(double) * ((size_t)nb * 16 * 80 + (size_t)nb * 16));
 #define K3_WAVE_LAUNCH(NBV)                                                                                            \
   do {                                                                                                                  \
-    if (!exact_b && lds32 > 48 * 1024)                                                                                  \
-      HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave32<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32)); \
     if (f16b) {                                                                                                          \
       HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_wave16<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
       KHG_LAUNCH(ctx, (k3_accumulate_wave16<NBV>), dim3(nblk), dim3(256), lds16, ctx->stream, a);                     \
     } else if (exact_b && f16a) KHG_LAUNCH(ctx, (k3_accumulate_wave<NBV, true>), dim3(nblk), dim3(256), lds, ctx->stream, a);    \
-    else if (exact_b) KHG_LAUNCH(ctx, (k3_accumulate_wave<NBV>), dim3(nblk), dim3(256), lds, ctx->stream, a);         \
-    else KHG_LAUNCH(ctx, (k3_accumulate_wave32<NBV>), dim3(nblk), dim3(256), lds32, ctx->stream, a);                  \
+    else KHG_LAUNCH(ctx, (k3_accumulate_wave<NBV>), dim3(nblk), dim3(256), lds, ctx->stream, a);                      \
     KHG_LAUNCH(ctx, (k3_wave_finalize<NBV>), dim3(np), dim3(256), 0, ctx->stream, a);                                 \
   } while (0)
       switch (nb) {
@@ -293,21 +288,25 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       }
 #undef K3_WAVE_LAUNCH
       }
-      if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+      if (comm_ && nparts_ > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm_, nullptr); if (rc) return rc; }
       }
       a.pdf0 = 0; a.npdf = m->P;
-      KHG_LAUNCH(ctx, k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a);
-    } else if (use_mfma) {
-      // fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block
+      KHG_LAUNCH(ctx, k3_wave_scalars, dim3(1), dim3(1024), 0, ctx->stream, a, cls_lo, cls_hi);
+      return KHG_OK;
+    };
+    // ---- fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block ----
+    auto run_mfma = [&](int cls_lo, int cls_hi, int maxG, bool second, void* comm_) -> int {
+      const int64_t avg_chunks = (Neff / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
       const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions
       // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
       // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
       int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
       if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
-      rc = make_items(ny, false, 0);
+      rc = make_items(ny, false, 0, cls_lo, cls_hi, second);
       if (rc) return rc;
-      for (int part = 0; part < nparts; ++part) {
-        const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      const int nparts_ = comm_ ? nparts : 1;
+      for (int part = 0; part < nparts_; ++part) {
+        const int p0 = (int)((int64_t)m->P * part / nparts_), np = (int)((int64_t)m->P * (part + 1) / nparts_) - p0;
         a.pdf0 = p0; a.npdf = np;
         const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
@@ -319,19 +318,24 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
           else if (maxG <= 64) KHG_LAUNCH(ctx, (k3_accumulate_mfma<20, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
           else KHG_LAUNCH(ctx, (k3_accumulate_mfma<20, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
         }
-        if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+        if (comm_ && nparts_ > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm_, nullptr); if (rc) return rc; }
       }
-      a.pdf0 = 0;
-    } else {
+      a.pdf0 = 0; a.npdf = m->P;
+      return KHG_OK;
+    };
+    // ---- the VALU form: any number of Gaussians, any dimension ----
+    auto run_valu = [&](int cls_lo, int cls_hi, int maxG, bool second, void* comm_) -> int {
+      const int64_t avg_chunks = (Neff / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
       const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)(m->KQ ? 4 * m->KQ : (m->D | 1)) + (maxG | 1) + 4);
       if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
       const void* k3fn = m->KQ == 10 ? (const void*)k3_accumulate<10> : m->KQ == 20 ? (const void*)k3_accumulate<20> : (const void*)k3_accumulate<0>;
       if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(k3fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(64, (avg_chunks + 3) / 4));
-      rc = make_items(ny, false, 0);
+      rc = make_items(ny, false, 0, cls_lo, cls_hi, second);
       if (rc) return rc;
-      for (int part = 0; part < nparts; ++part) {
-        const int p0 = (int)((int64_t)m->P * part / nparts), np = (int)((int64_t)m->P * (part + 1) / nparts) - p0;
+      const int nparts_ = comm_ ? nparts : 1;
+      for (int part = 0; part < nparts_; ++part) {
+        const int p0 = (int)((int64_t)m->P * part / nparts_), np = (int)((int64_t)m->P * (part + 1) / nparts_) - p0;
         a.pdf0 = p0; a.npdf = np;
         const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
         {
@@ -340,10 +344,28 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
           else if (m->KQ == 20) KHG_LAUNCH(ctx, k3_accumulate<20>, dim3(nblk), dim3(256), lds, ctx->stream, a);
           else KHG_LAUNCH(ctx, k3_accumulate<0>, dim3(nblk), dim3(256), lds, ctx->stream, a);
         }
-        if (comm && nparts > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm, nullptr); if (rc) return rc; }
+        if (comm_ && nparts_ > 1) { rc = accs_allreduce_pieces(ctx, acc, m, p0, np, comm_, nullptr); if (rc) return rc; }
       }
-      a.pdf0 = 0;
+      a.pdf0 = 0; a.npdf = m->P;
+      return KHG_OK;
+    };
+    // Form per pdf: the wave form takes every pdf of <= 64 Gaussians (D <= 40); what is left -- a few pdfs a split grew, or a model
+    // of wide pdfs throughout -- goes to the chunk-per-block MFMA form (<= 256 Gaussians at D <= 40, <= 128 at D <= 80) or the VALU form.
+    int maxG = 0, maxG_lo = 0, n_hi = 0;
+    for (int p = 0; p < m->P; ++p) {
+      const int Gp = m->gauss_off[p + 1] - m->gauss_off[p];
+      maxG = std::max(maxG, Gp);
+      if (Gp <= 64) maxG_lo = std::max(maxG_lo, Gp); else ++n_hi;
     }
+    const bool mfma_ok = (maxG <= 128 || (maxG <= 256 && m->KQ == 10)) && k3form != 2 && m->KQ != 0;
+    const bool wave_ok = m->KQ == 10 && k3form == 0 && maxG_lo > 0;
+    if (wave_ok && n_hi == 0) rc = run_wave(0, INT_MAX, maxG, comm);
+    else if (wave_ok) {
+      rc = run_wave(0, 64, maxG_lo, nullptr);                  // (with an exchange: its pieces follow the second class's kernels)
+      if (!rc) rc = mfma_ok ? run_mfma(64, INT_MAX, maxG, true, comm) : run_valu(64, INT_MAX, maxG, true, comm);
+    } else if (mfma_ok) rc = run_mfma(0, INT_MAX, maxG, false, comm);
+    else rc = run_valu(0, INT_MAX, maxG, false, comm);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
   } else if (comm && nparts > 1) {
     // a rank without frames launches nothing but takes part in the same collectives, in the same order, as every other rank: the

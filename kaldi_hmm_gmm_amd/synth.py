@@ -52,12 +52,15 @@ class SynthModel:
         return self.id2pdf.shape[0] - 1
 
 
-def make_model(num_pdfs, gauss, dim, seed=20230414, ragged=False, self_loop_prob=0.75, mean_scale=3.0):
+def make_model(num_pdfs, gauss, dim, seed=20230414, ragged=False, self_loop_prob=0.75, mean_scale=3.0, gauss_counts=None):
     """mean_scale: spread of the Gaussian means (3.0 = a trained-like model, Gaussians ~27 sigma apart at D = 40).
     A small spread (0.1 .. 0.3) gives CONFUSABLE pdfs, the regime of a recipe's first realign passes: the best path leaves a narrow
     beam now and then, the reference's pruning decides the answer and khg_align must follow it token for token."""
     rng = np.random.default_rng(seed)
-    if ragged:
+    if gauss_counts is not None:           # explicit Gaussians per pdf (a model some of whose pdfs a split has grown)
+        g = np.asarray(gauss_counts, np.int64)
+        assert g.shape == (num_pdfs,) and (g >= 1).all()
+    elif ragged:
         g = rng.integers(max(1, gauss // 2), gauss + 1, size=num_pdfs)
     else:
         g = np.full(num_pdfs, gauss)

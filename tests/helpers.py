@@ -5,8 +5,8 @@ from kaldi_hmm_gmm_amd import synth
 from oracle import oracle as orc
 
 
-def build(num_pdfs, gauss, dim, n_utt, seed=1, ragged=False, min_phones=2, max_phones=6, tscale=1.0, slscale=0.1, transcripts="uniform"):
-    m = synth.make_model(num_pdfs, gauss, dim, seed=20230414 + seed, ragged=ragged)
+def build(num_pdfs, gauss, dim, n_utt, seed=1, ragged=False, min_phones=2, max_phones=6, tscale=1.0, slscale=0.1, transcripts="uniform", gauss_counts=None):
+    m = synth.make_model(num_pdfs, gauss, dim, seed=20230414 + seed, ragged=ragged, gauss_counts=gauss_counts)
     gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
     om = orc.OModel(m.gauss_off, gc, m.means_invvars, m.inv_vars)
     ut = synth.make_utts(m, n_utt, seed=seed, min_phones=min_phones, max_phones=max_phones, transcripts=transcripts)

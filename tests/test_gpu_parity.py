@@ -403,6 +403,37 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
     np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
 
 
+@pytest.mark.parametrize("big", [(130,), (70, 256), (300,)])
+def test_acc_stats_form_is_chosen_per_pdf(ctx, big):
+    """A model whose pdfs hold <= 64 Gaussians except for a few that Split (csrc/diag-gmm.cc:780-851) has grown: the wave form keeps
+    every pdf it can take, only the grown ones go to the chunk-per-block MFMA form (<= 256 Gaussians) or the VALU form (beyond) --
+    one launch per class, the same accumulator block.  Against the oracle (csrc/mle-diag-gmm.cc:123-158, csrc/diag-gmm.cc:368-392);
+    the <= 64-Gaussian pdfs' statistics are bit-identical to those of the same pdfs in a model without the grown ones' frames."""
+    from kaldi_hmm_gmm_amd import DeviceAccs
+    P, D = 45, 40
+    counts = np.full(P, 64)
+    counts[::7] = 33
+    for k, g in enumerate(big):
+        counts[5 + 11 * k] = g
+    m, gc, om, ut, cost = build(P, 64, D, n_utt=40, seed=13, max_phones=6, gauss_counts=counts)
+    dm, tm, us = _device(ctx, m, gc, ut, cost)
+    us.upload_ali(ut.ref_ali)
+    accs = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, accs, weight=1.0)
+    got = accs.download()
+    oa = orc.OAccs(int(m.gauss_off[-1]), D, m.num_tids)
+    for u in range(us.n_utt):
+        orc.acc_stats_ali(om, m.id2pdf, utt_feats(ut, u), ut.ref_ali[ut.frame_off[u]: ut.frame_off[u + 1]], oa)
+    assert (got["trans_acc"] == oa.trans_acc).all() and got["total_frames"] == oa.total_frames
+    assert got["total_log_like"] == pytest.approx(oa.total_log_like, rel=2e-6)
+    np.testing.assert_allclose(got["occ"], oa.occ, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["mean_acc"], oa.mean_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.mean_acc).max())
+    np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
+    per_pdf = np.bincount(m.id2pdf[ut.ref_ali], minlength=P)
+    np.testing.assert_allclose(np.add.reduceat(got["occ"], m.gauss_off[:-1].astype(np.int64)), per_pdf, rtol=1e-5, atol=1e-4)
+    assert per_pdf[[5 + 11 * k for k in range(len(big))]].min() > 0, "the grown pdfs hold frames"
+
+
 @pytest.mark.parametrize("k3_form", ["wave", "wave_b64", "wave_f32", "block", "valu"])
 @pytest.mark.parametrize("P,G,D", [(60, 64, 40), (300, 24, 39)])
 def test_acc_stats_with_a_pdf_far_above_the_average(ctx, P, G, D, k3_form, opt):
@@ -562,42 +593,6 @@ def test_acc_stats_overlapping_gaussians_vs_oracle(ctx, P, G, D, k3_form, opt):
         g = np.exp(ll - ll.max(1, keepdims=True))
         occ64[a:b] = 0.75 * (g / g.sum(1, keepdims=True)).sum(0)
     np.testing.assert_allclose(got["occ"], occ64, rtol=2e-4, atol=1e-6)
-
-
-def test_acc_stats_fp32_phase_b_option(ctx, opt):
-    """Option k3_phase_b = 1 (k3_accumulate_wave32: gamma . x on the fp32 matrix pipe, 256-frame fp32 partial sums widened into a
-    per-workgroup fp64 image): within the statistics' tolerance of the default (products exact in fp64), transition counts
-    and frame totals identical, and run-to-run reproducible bit for bit."""
-    from kaldi_hmm_gmm_amd import DeviceAccs
-
-    m, gc, om, ut, cost = build(20, 64, 40, n_utt=120, seed=33, max_phones=8)
-    dm, tm, us = _device(ctx, m, gc, ut, cost)
-    us.upload_ali(ut.ref_ali)
-    opt("k3_phase_a", 1)          # the fp32-pipe kernel keeps the fp32 phase A: compare it with the exact form on the same phase A
-
-    def run():
-        accs = DeviceAccs(ctx, dm, tm)
-        us.acc_stats(dm, tm, accs, weight=0.5)
-        st = accs.download()
-        accs.close()
-        return st
-
-    exact = run()
-    opt("k3_phase_b", 1)
-    a, b = run(), run()
-    for k in ("occ", "mean_acc", "var_acc", "trans_acc"):
-        assert np.array_equal(a[k], b[k]), k
-    assert np.array_equal(a["trans_acc"], exact["trans_acc"]) and a["total_frames"] == exact["total_frames"]
-    assert a["total_log_like"] == exact["total_log_like"]           # phase A and the softmax are the same code
-    np.testing.assert_allclose(a["occ"], exact["occ"], rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(a["mean_acc"], exact["mean_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["mean_acc"]).max())
-    np.testing.assert_allclose(a["var_acc"], exact["var_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["var_acc"]).max())
-    assert not np.array_equal(a["mean_acc"], exact["mean_acc"])      # it really is the other kernel
-    for ny in ("3",):                                                # several blocks per pdf: parked slices, same tolerance
-        opt("k3_ny", int(ny))
-        c = run()
-        np.testing.assert_allclose(c["mean_acc"], exact["mean_acc"], rtol=2e-5, atol=2e-5 * np.abs(exact["mean_acc"]).max())
-        np.testing.assert_allclose(c["occ"], exact["occ"], rtol=2e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("P,G,D,n_utt", [(12, 40, 23, 60), (300, 8, 13, 400), (3, 4, 40, 5)])
