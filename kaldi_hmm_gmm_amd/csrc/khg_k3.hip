@@ -295,12 +295,13 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       return KHG_OK;
     };
     // ---- fp32 + fp64 MFMA form; fewer, longer blocks: the fp64 accumulators stay in registers per block ----
-    auto run_mfma = [&](int cls_lo, int cls_hi, int maxG, bool second, void* comm_) -> int {
+    auto run_mfma = [&](int cls_lo, int cls_hi, int maxG, int n_cls, bool second, void* comm_) -> int {
       const int64_t avg_chunks = (Neff / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
       const size_t lds = sizeof(float) * ((size_t)4 * K3_CHUNK * 2 * m->KQ + 5 * K3_CHUNK);   // 4 planes [64][KH] + reductions
       // slices per pdf: every block ends with one fp64 atomic per accumulator cell (G*(2D+1) of them), so
       // use as few blocks as still fill the chip (~4096 = 256 CUs x 8 blocks x 2 rounds)
-      int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + m->P - 1) / m->P));
+      // (a class of a few pdfs -- the ones a split has grown -- is cut finer: one block walking a whole bucket is a latency of its own)
+      int ny = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, avg_chunks), (4096 + n_cls - 1) / std::max(1, n_cls)));
       if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
       rc = make_items(ny, false, 0, cls_lo, cls_hi, second);
       if (rc) return rc;
@@ -308,7 +309,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       for (int part = 0; part < nparts_; ++part) {
         const int p0 = (int)((int64_t)m->P * part / nparts_), np = (int)((int64_t)m->P * (part + 1) / nparts_) - p0;
         a.pdf0 = p0; a.npdf = np;
-        const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
+        const unsigned nblk = (unsigned)((int64_t)std::min(np, n_cls) * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
           if (m->KQ == 10 && maxG <= 64) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
@@ -324,7 +325,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       return KHG_OK;
     };
     // ---- the VALU form: any number of Gaussians, any dimension ----
-    auto run_valu = [&](int cls_lo, int cls_hi, int maxG, bool second, void* comm_) -> int {
+    auto run_valu = [&](int cls_lo, int cls_hi, int maxG, int n_cls, bool second, void* comm_) -> int {
       const int64_t avg_chunks = (Neff / std::max(1, m->P) + K3_CHUNK - 1) / K3_CHUNK;
       const size_t lds = sizeof(float) * (size_t)K3_CHUNK * ((size_t)(m->KQ ? 4 * m->KQ : (m->D | 1)) + (maxG | 1) + 4);
       if (lds > 160 * 1024) return khg_set_error(KHG_E_UNSUPPORTED, "khg_acc_stats: pdf too large for the LDS chunk buffers");
@@ -337,7 +338,7 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       for (int part = 0; part < nparts_; ++part) {
         const int p0 = (int)((int64_t)m->P * part / nparts_), np = (int)((int64_t)m->P * (part + 1) / nparts_) - p0;
         a.pdf0 = p0; a.npdf = np;
-        const unsigned nblk = (unsigned)((int64_t)np * ny + k3_extra_blocks);
+        const unsigned nblk = (unsigned)((int64_t)std::min(np, n_cls) * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
           if (m->KQ == 10) KHG_LAUNCH(ctx, k3_accumulate<10>, dim3(nblk), dim3(256), lds, ctx->stream, a);
@@ -362,9 +363,9 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
     if (wave_ok && n_hi == 0) rc = run_wave(0, INT_MAX, maxG, comm);
     else if (wave_ok) {
       rc = run_wave(0, 64, maxG_lo, nullptr);                  // (with an exchange: its pieces follow the second class's kernels)
-      if (!rc) rc = mfma_ok ? run_mfma(64, INT_MAX, maxG, true, comm) : run_valu(64, INT_MAX, maxG, true, comm);
-    } else if (mfma_ok) rc = run_mfma(0, INT_MAX, maxG, false, comm);
-    else rc = run_valu(0, INT_MAX, maxG, false, comm);
+      if (!rc) rc = mfma_ok ? run_mfma(64, INT_MAX, maxG, n_hi, true, comm) : run_valu(64, INT_MAX, maxG, n_hi, true, comm);
+    } else if (mfma_ok) rc = run_mfma(0, INT_MAX, maxG, m->P, false, comm);
+    else rc = run_valu(0, INT_MAX, maxG, m->P, false, comm);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
   } else if (comm && nparts > 1) {
