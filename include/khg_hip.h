@@ -71,13 +71,11 @@ int khg_ctx_get_timings(khg_ctx *ctx, char *names, int64_t names_cap, float *ms,
  *                    residuals, |v - (v1 + v2 2^-11)| <= 2^-23 |v|) and two accumulators (main + cross, combined by one fma per
  *                    Gaussian): worst case 2^-21 per term, measured error BELOW the fp32 chain's (profiles/r2_probe_f16x2.txt);
  *                    same common domain;
- *   KHG_K1_BF16X3    both operands split exactly into three bf16 pieces, the six partial products of weight >= 2^-16 on
- *                    v_mfma_f32_32x32x16_bf16 with fp32 accumulation (profiles/r2_probe_bf16x3.txt); same domain rule;
+ *   (value 1, KHG_K1_BF16X3 of rounds 2-5 -- three exact bf16 pieces, six products -- was removed in round 6: KHG_E_ARG)
  *   KHG_K1_FP32_PDF / KHG_K1_FP32_UTT   fp32 MFMA (v_mfma_f32_16x16x4_f32), pdf-major / utterance-major tiling: bit for bit the
  *                    per-Gaussian chain s = gconst; s = fmaf(M[d], x[d], s) ...; s = fmaf(-V[d]/2, x[d]^2, s) ... in k order.
- * The environment variable KHG_K1 = f16x2s | f16x2 | bf16x3 | pdf | utt seeds the setting at khg_ctx_create (A/B runs). */
+ * The environment variable KHG_K1 = f16x2s | f16x2 | pdf | utt seeds the setting at khg_ctx_create (A/B runs). */
 #define KHG_K1_AUTO 0
-#define KHG_K1_BF16X3 1
 #define KHG_K1_FP32_PDF 2
 #define KHG_K1_FP32_UTT 3
 #define KHG_K1_F16X2 4
@@ -88,7 +86,7 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
  * has no counterpart for -- its kernels are Eigen expressions).  Values are validated (KHG_E_ARG).  An option takes effect at the
  * next call that plans or launches the kernel it names; plans already built for an utterance set (chunk order, K1P slices) are
  * kept.  The environment variables in brackets only seed the defaults, once, at khg_ctx_create (A/B runs of an unmodified caller). */
-#define KHG_OPT_K1_FORM 0        /* KHG_K1_* above                                                              [KHG_K1=f16x2s|f16x2|bf16x3|pdf|utt] */
+#define KHG_OPT_K1_FORM 0        /* KHG_K1_* above                                                              [KHG_K1=f16x2s|f16x2|pdf|utt] */
 #define KHG_OPT_K1_ORDER 1       /* launch order of K1 workgroups: 0 frame tiles x pdfs descending, 1 utterance order, 2 ascending,
                                     3 frame tiles descending                                                    [KHG_K1_ORDER=desc|none|asc|tiles] */
 #define KHG_OPT_K1_NF 2          /* fp32 utterance-major K1: 16-frame tiles per wave at D <= 40 (0 = 6, or 5)     [KHG_K1_NF] */

@@ -171,7 +171,7 @@ static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
   {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 3}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
-  if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi)
+  if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi || (opt == KHG_OPT_K1_FORM && value == 1))      // (1: the removed bf16x3 form)
     return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: option " + std::to_string(opt) + " takes values " + std::to_string(k_opt_range[opt].lo) + " .. " + std::to_string(k_opt_range[opt].hi));
   c->opt[opt] = value;
   return KHG_OK;
@@ -190,7 +190,7 @@ extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) { return khg_ctx_set_op
 // listed.  Everything else goes through khg_ctx_set_option.
 static void ctx_defaults_from_env(khg_ctx* c) {
   static const struct { const char* name; int opt; const char* words; } tab[] = {
-    {"KHG_K1", KHG_OPT_K1_FORM, "auto=0,bf16x3=1,pdf=2,fp32=2,utt=3,f16x2=4,f16x2s=5"},
+    {"KHG_K1", KHG_OPT_K1_FORM, "auto=0,pdf=2,fp32=2,utt=3,f16x2=4,f16x2s=5"},
     {"KHG_K1_ORDER", KHG_OPT_K1_ORDER, "desc=0,none=1,asc=2,tiles=3"},
     {"KHG_K1_NF", KHG_OPT_K1_NF, ""}, {"KHG_K1P_TS", KHG_OPT_K1P_TS, ""}, {"KHG_K1_INTERLEAVE", KHG_OPT_K1_INTERLEAVE, ""},
     {"KHG_K1B_DBG", KHG_OPT_K1_DBG, ""}, {"KHG_K2_INORDER", KHG_OPT_K2_INORDER, ""}, {"KHG_K2_KS", KHG_OPT_K2_KS, ""},
@@ -445,7 +445,6 @@ int model_pack(khg_ctx* ctx, khg_model* m) {
   if (m->KQ == 0) {
     // any-dimension model (D > 80): no tile images; K3 still reads -0.5 * inv_vars
     m->KS = 0;
-    m->wimgb_valid = false;
     m->wimgh_ex.clear(); m->wimgs_key.clear(); m->ubound_valid = false; m->wmax.clear(); m->k3_xb.clear();
     const int64_t n = m->sumG * D;
     KHG_LAUNCH(ctx, k0_nhalf, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, m->iv_d, n, m->nhiv_d);
@@ -461,7 +460,6 @@ int model_pack(khg_ctx* ctx, khg_model* m) {
     m->wimg_tiles = nt;
   }
   m->KS = m->KQ == 10 ? 5 : 10;
-  m->wimgb_valid = false;
   std::vector<int32_t> tile_pdf((size_t)nt);   // tile -> pdf map for the pack kernel
   for (int p = 0; p < P; ++p)
     for (int t = m->pdf_tile_off[p]; t < m->pdf_tile_off[p + 1]; ++t) tile_pdf[(size_t)t] = p;
@@ -530,15 +528,14 @@ extern "C" int khg_model_create(khg_ctx* ctx, int32_t P, int32_t D, const int32_
 extern "C" int khg_model_invalidate(khg_model* m) {
   if (!m) return khg_set_error(KHG_E_ARG, "khg_model_invalidate: model is NULL");
   ++m->version;
-  m->wimgb_valid = false;
   m->wimgh_ex.clear(); m->wimgs_key.clear(); m->ubound_valid = false; m->wmax.clear(); m->k3_xb.clear();
   return KHG_OK;
 }
 extern "C" int khg_model_destroy(khg_model* m) {
   if (!m) return KHG_OK;
   { std::lock_guard<std::mutex> lk(g_model_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
-  m->wimgh_sync.destroy(); m->wimgb_sync.destroy(); m->wimgs_sync.destroy();
-  DEVFREE(m->wimg_d); DEVFREE(m->wimgb_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->stats_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
+  m->wimgh_sync.destroy(); m->wimgs_sync.destroy();
+  DEVFREE(m->wimg_d); DEVFREE(m->wimgh_d); DEVFREE(m->wimgs_d); DEVFREE(m->ubound_d); DEVFREE(m->stats_d); DEVFREE(m->k3_ex_d); DEVFREE(m->tile_pdf_d); DEVFREE(m->k4_res_d); DEVFREE(m->pdf_tile_off_d); DEVFREE(m->gauss_off_d);
   DEVFREE(m->gconsts_d); DEVFREE(m->miv_d); DEVFREE(m->iv_d); DEVFREE(m->nhiv_d); DEVFREE(m->weights_d);
   delete m;
   return KHG_OK;

@@ -172,14 +172,12 @@ struct khg_model {
   float* weights_d = nullptr;   // only the device M-step needs them (khg_model_set_weights)
   bool has_weights = false;
   int32_t wimg_tiles = 0;       // tiles wimg_d was allocated for
-  char* wimgb_d = nullptr;      // bf16x3 K1 image (khg_k1_bf16x3.hip.inc), k1b_tile_bytes(KS) per 32-Gaussian tile
-  int32_t wimgb_tiles = 0, KS = 0;
-  bool wimgb_valid = false;       // packed from the current parameters (lazily: only the bf16x3 form reads it)
+  int32_t KS = 0;
   // f16x2 K1 image (khg_k1_f16x2.hip.inc): packed lazily by khg_loglikes with the scale exponents of the utterance set
   char* wimgh_d = nullptr;
   int32_t wimgh_tiles = 0;
   std::vector<int32_t> wimgh_ex;   // exponents the image was packed with (empty: stale)
-  ImgSync wimgh_sync, wimgb_sync;
+  ImgSync wimgh_sync;
   // f16x2s K1 image (khg_k1_f16x2s.hip.inc): packed lazily with the weight exponents ew[k] = S - ex[k] and gconst 2^S
   char* wimgs_d = nullptr;
   int32_t wimgs_tiles = 0;
@@ -243,15 +241,14 @@ struct khg_utts {
   khg_model* band_model = nullptr; int band_ks = 0; size_t band_lds = 0; uint64_t band_serial = 0, band_version = 0; std::vector<int32_t> band_key;   // ... and which model / parameter version / fp16 image they belong to int band_ks = 0; size_t band_lds = 0;
   int tiles_reach = -1;            // whether the walk lists carry those first frames (reachable-only K1) or zeros
   std::vector<int32_t> tiles_pto;  // the model tile layout (pdf_tile_off) the walk lists were built for
-  int64_t* tile2_off_d = nullptr; int32_t* tiles2_d = nullptr; std::vector<int32_t> tiles2_pto; int tiles2_reach = -1;   // bf16x3: pair walk
   float* ll_d = nullptr; int64_t ll_total = 0; bool ll_valid = false;
   // K1, pdf-major form: repacked features (once), work plan (per reachable flag)
   float* xpl_d = nullptr; int64_t* utt_xtile_off_d = nullptr; int32_t xpl_kq = 0;
   K1pEntry* p_ents_d = nullptr; K1pSlice* p_slices_d = nullptr; int32_t p_nslices = 0; int p_reach = -1; int32_t p_P = -1;
   int32_t p_grp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // slices per block count (index 1..8); the plan also depends on the model's gauss_off
   std::vector<int32_t> p_goff;
-  // K1, bf16x3 form: B fragments of the features (once), workgroup chunks
-  k1b_u32x4* xb3_d = nullptr; int64_t* utt_x32_off_d = nullptr; int32_t xb3_ks = 0;
+  // K1, split forms: the set's 32-frame tile layout, workgroup chunks
+  int64_t* utt_x32_off_d = nullptr;
   K1bChunk* bchunks_d = nullptr; int32_t n_bchunks = 0, bchunk_nt = 0;
   int32_t* x32_utt_d = nullptr; int64_t n_x32 = 0;        // 32-frame tile -> utterance
   // K1, f16x2 form: B fragments packed with the scale exponents xh_ex (per k = 2 d + kind)

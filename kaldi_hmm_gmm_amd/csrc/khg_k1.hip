@@ -4,7 +4,7 @@
 
 #include "khg_k1_loglikes.hip.inc"
 #include "khg_k1_pdfmajor.hip.inc"
-#include "khg_k1_bf16x3.hip.inc"
+#include "khg_k1_split_common.hip.inc"
 #include "khg_k1_f16x2.hip.inc"
 #include "khg_k1_wide.hip.inc"
 #include "khg_k1_f16x2s.hip.inc"
@@ -165,7 +165,7 @@ static int loglikes_pdf_major(khg_ctx* ctx, const khg_model* m, khg_utts* u, boo
 // per-utterance W-tile walk for this model's tile layout (it only changes when the number of Gaussians of some pdf
 // crosses a multiple of 32): for every pdf on the utterance's list its 32-Gaussian tiles in order.  Entry = tile id
 // (bits 0-21) | first needed 16-frame tile of the pdf, clamped to 127 (bits 22-28; 0 unless reachable_only) |
-// last-tile-of-pdf flag (bit 31).  Shared by the utterance-major fp32 kernel and the bf16x3 kernel.
+// last-tile-of-pdf flag (bit 31).  Shared by the utterance-major fp32 kernel and the f16x2 kernel.
 static int ensure_walk(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reachable_only) {
   if (u->tiles_pto == m->pdf_tile_off && u->tiles_reach == (int)reachable_only) return KHG_OK;
   if (m->ntiles >= (1 << 22)) return khg_set_error(KHG_E_UNSUPPORTED, "khg_loglikes: more than 4M W tiles");
@@ -191,7 +191,7 @@ static int ensure_walk(khg_ctx* ctx, const khg_model* m, khg_utts* u, bool reach
   return KHG_OK;
 }
 
-// 32-frame tile layout of the set shared by the bf16x3 / f16x2 / f16x2s forms: tile offsets per utterance, tile -> utterance.
+// 32-frame tile layout of the set shared by the f16x2 / f16x2s forms: tile offsets per utterance, tile -> utterance.
 static int ensure_x32_layout(khg_ctx* ctx, khg_utts* u) {
   if (u->utt_x32_off_d) return KHG_OK;
   std::vector<int64_t> xoff((size_t)u->n_utt + 1, 0);
@@ -242,68 +242,6 @@ static int ensure_x32(khg_ctx* ctx, khg_utts* u, int NTMAX) {
   return KHG_OK;
 }
 
-// K1 on the bf16 matrix cores (khg_k1_bf16x3.hip.inc): B fragments of the features (once per set), chunks, walk.
-static int loglikes_bf16x3(khg_ctx* ctx, const khg_model* mc, khg_utts* u, bool reachable_only) {
-  khg_model* m = const_cast<khg_model*>(mc);
-  const int KS = m->KS, NTMAX = KS == 5 ? 2 : 1;
-  int rc = ensure_x32(ctx, u, NTMAX);
-  if (rc) return rc;
-  if (!m->wimgb_valid) {          // the bf16x3 image of the current parameters
-    if (!m->wimgb_d || m->wimgb_tiles < m->ntiles) {
-      DEVFREE(m->wimgb_d);
-      rc = dev_alloc(&m->wimgb_d, (size_t)m->ntiles * k1b_tile_bytes(KS));
-      if (rc) return rc;
-      m->wimgb_tiles = m->ntiles;
-    }
-    rc = m->wimgb_sync.before_pack(ctx->stream);
-    if (rc) return rc;
-    KernelTimer kt(ctx, "k0b_pack_tiles");
-    if (KS == 5) KHG_LAUNCH(ctx, k0b_pack_tiles<5>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
-    else KHG_LAUNCH(ctx, k0b_pack_tiles<10>, dim3(m->ntiles), dim3(256), 0, ctx->stream, m->gconsts_d, m->miv_d, m->iv_d, m->gauss_off_d, m->pdf_tile_off_d, m->tile_pdf_d, m->D, m->wimgb_d, ctx->err_flag_d);
-    HIPCHK(hipGetLastError());
-    rc = m->wimgb_sync.after_pack(ctx->stream);
-    if (rc) return rc;
-    m->wimgb_valid = true;
-  }
-  if (!u->xb3_d || u->xb3_ks != KS) {
-    DEVFREE(u->xb3_d);
-    const int64_t nx = u->n_x32;
-    rc = u_alloc(u, &u->xb3_d, (size_t)std::max<int64_t>(nx, 1) * 3 * KS * 64);
-    if (!rc && nx > 0) {
-      const int gb = (int)std::min<int64_t>(65535, (nx * KS * 64 + 255) / 256);
-      if (KS == 5) KHG_LAUNCH(ctx, k1b_pack_x<5>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
-      else KHG_LAUNCH(ctx, k1b_pack_x<10>, dim3(gb), dim3(256), 0, ctx->stream, u->feats_d, u->frame_off_d, u->utt_x32_off_d, u->x32_utt_d, nx, u->D, u->xb3_d);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) rc = khg_set_error(KHG_E_HIP, hipGetErrorString(e));
-    }
-    if (rc) return rc;
-    u->xb3_ks = KS;
-  }
-  rc = ensure_walk(ctx, m, u, reachable_only);
-  if (rc) return rc;
-  K1bArgs a;
-  a.xb = u->xb3_d; a.utt_xtile_off = u->utt_x32_off_d; a.frame_off = u->frame_off_d; a.chunks = u->bchunks_d;
-  a.wimg = m->wimgb_d; a.utt_tile_off = u->tile_off_d; a.utt_tiles = u->tiles_d;
-  a.ll = u->ll_d; a.ll_off = u->ll_off_d; a.err_flag = ctx->err_flag_d;
-  a.dbg = ctx->opt[KHG_OPT_K1_DBG];
-  if (u->n_bchunks > 0) {
-    const size_t lds = (size_t)k1b_ring(KS) * k1b_group(KS) * k1b_tile_bytes(KS);
-    const void* fn = KS == 5 ? (const void*)k1b_loglikes<5, 2> : (const void*)k1b_loglikes<10, 1>;
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rc = m->wimgb_sync.before_read(ctx->stream);
-    if (rc) return rc;
-    {
-      KernelTimer kt(ctx, "k1_loglikes");
-      if (KS == 5) KHG_LAUNCH(ctx, (k1b_loglikes<5, 2>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-      else KHG_LAUNCH(ctx, (k1b_loglikes<10, 1>), dim3(u->n_bchunks), dim3(512), lds, ctx->stream, a);
-    }
-    HIPCHK(hipGetLastError());
-    rc = m->wimgb_sync.after_read(ctx->stream);
-    if (rc) return rc;
-  }
-  u->ll_valid = true;
-  return KHG_OK;
-}
 
 // column maxima of |a[n][D]| -> host
 static int absmax_cols(khg_ctx* ctx, const float* a_d, int64_t n, int D, std::vector<float>* out) {
@@ -359,7 +297,7 @@ int k1_maxima(khg_ctx* ctx, khg_model* m, khg_utts* u, std::vector<float>* xk) {
   for (int d = 0; d < D; ++d) { (*xk)[(size_t)2 * d] = u->xmax[(size_t)d]; (*xk)[(size_t)2 * d + 1] = u->xmax[(size_t)d] * u->xmax[(size_t)d]; }
   return KHG_OK;
 }
-// The split forms (f16x2, bf16x3) fold the log-sum-exp's subtraction into an fma (k1_exp2_le1): valid while every
+// The split forms (f16x2, f16x2s) fold the log-sum-exp's subtraction into an fma (k1_exp2_le1): valid while every
 // log-likelihood term sum stays below 2^28 in magnitude (khg_k1_f16x2.hip.inc, "Domain").
 static bool k1_split_domain(const khg_model* m, const std::vector<float>& xk) {
   double bound = (double)m->gcmax;
@@ -691,7 +629,7 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reac
     if (rc) return rc;
   }
   {
-    // which K1: bf16x3 (default: the bf16 matrix cores at fp32 accuracy), or one of the fp32-MFMA forms -- pdf-major (pdfs of
+    // which K1: f16x2s (default: the fp16 matrix cores at fp32 accuracy) -> f16x2 -> one of the fp32-MFMA forms -- pdf-major (pdfs of
     // <= 128 Gaussians) / utterance-major -- whose per-Gaussian fmaf chain is pinned bit for bit by the tests
     int form = ctx->opt[KHG_OPT_K1_FORM];
     if (form == KHG_K1_AUTO) form = KHG_K1_F16X2S;
@@ -706,13 +644,6 @@ static int loglikes_impl(khg_ctx* ctx, const khg_model* m, khg_utts* u, int reac
       rc = loglikes_f16x2(ctx, const_cast<khg_model*>(m), u, reachable_only);
       if (rc <= 0) return rc;
       form = KHG_K1_FP32_PDF;        // magnitudes outside the split forms' domain
-    }
-    if (form == KHG_K1_BF16X3) {
-      std::vector<float> xk;
-      rc = k1_maxima(ctx, const_cast<khg_model*>(m), u, &xk);
-      if (rc) return rc;
-      if (k1_split_domain(m, xk)) return loglikes_bf16x3(ctx, m, u, reachable_only);
-      form = KHG_K1_FP32_PDF;
     }
     int maxG = 0;
     for (int p = 0; p < m->P; ++p) maxG = std::max(maxG, m->gauss_off[p + 1] - m->gauss_off[p]);

@@ -67,7 +67,7 @@ struct KContext {
   void sync() { Check(NoGil([&] { return khg_ctx_sync(h); })); }
   void set_timing(bool on) { Check(khg_ctx_set_timing(h, on ? 1 : 0)); }
   void set_k1_form(const std::string& f) {
-    int v = f == "auto" ? KHG_K1_AUTO : f == "bf16x3" ? KHG_K1_BF16X3 : (f == "pdf" || f == "fp32") ? KHG_K1_FP32_PDF : f == "utt" ? KHG_K1_FP32_UTT : f == "f16x2" ? KHG_K1_F16X2 : f == "f16x2s" ? KHG_K1_F16X2S : -1;
+    int v = f == "auto" ? KHG_K1_AUTO : (f == "pdf" || f == "fp32") ? KHG_K1_FP32_PDF : f == "utt" ? KHG_K1_FP32_UTT : f == "f16x2" ? KHG_K1_F16X2 : f == "f16x2s" ? KHG_K1_F16X2S : -1;
     if (v < 0) throw py::key_error(f);
     Check(khg_ctx_set_k1_form(h, v));
   }

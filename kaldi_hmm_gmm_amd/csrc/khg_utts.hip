@@ -230,7 +230,6 @@ extern "C" int khg_utts_set_pdf_list(khg_utts* u, int32_t n, const int32_t* pdfs
   plan_ll(u);
   DEVFREE(u->pdf_off_d); DEVFREE(u->pdfs_d); DEVFREE(u->ll_off_d); DEVFREE(u->ll_d); DEVFREE(u->chunks_d); DEVFREE(u->wchunks_d);
   DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d); u->tiles_pto.clear(); u->tiles_reach = -1;
-  DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d); u->tiles2_pto.clear(); u->tiles2_reach = -1;
   DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d); u->p_reach = -1;
   // the default K1's per-set unit table is indexed through pdf_off, and the id range check is cached per model size: both are stale now
   DEVFREE(u->sunits_d); u->sunits_pto.clear(); u->sunits_reach = -1;
@@ -246,7 +245,6 @@ extern "C" int khg_utts_features_changed(khg_utts* u) {
   u->xmax.clear();
   u->xs_ks = 0; u->xs_ex.clear();
   u->xh_ks = 0; u->xh_ex.clear();
-  u->xb3_ks = 0;
   u->ll_valid = false;
   return KHG_OK;
 }
@@ -277,7 +275,7 @@ extern "C" int khg_utts_destroy(khg_utts* u) {
   DEVFREE(u->in_src_d); DEVFREE(u->in_col_d); DEVFREE(u->in_tid_d); DEVFREE(u->in_olabel_d); DEVFREE(u->out_inidx_d);
   DEVFREE(u->in_w_d); DEVFREE(u->final_d); DEVFREE(u->chunks_d); DEVFREE(u->ll_d); DEVFREE(u->tile_off_d); DEVFREE(u->tiles_d);
   DEVFREE(u->xpl_d); DEVFREE(u->utt_xtile_off_d); DEVFREE(u->p_ents_d); DEVFREE(u->p_slices_d);
-  DEVFREE(u->xb3_d); DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d); DEVFREE(u->xh_d); DEVFREE(u->xh_ex_d); DEVFREE(u->tile2_off_d); DEVFREE(u->tiles2_d);
+  DEVFREE(u->utt_x32_off_d); DEVFREE(u->bchunks_d); DEVFREE(u->x32_utt_d); DEVFREE(u->xh_d); DEVFREE(u->xh_ex_d);
   DEVFREE(u->xs_d); DEVFREE(u->xs_ex_d); DEVFREE(u->schunks_d); DEVFREE(u->sunits_d);
   DEVFREE(u->bp_d); DEVFREE(u->bp_off_d); DEVFREE(u->path_off_d); DEVFREE(u->words_off_d);
   DEVFREE(u->ali2_d); DEVFREE(u->unc_d); DEVFREE(u->sub_off_d);

@@ -1,6 +1,6 @@
 """The randomised sweeps and the larger end-to-end check ON THE RECORD (they only existed as manual scripts):
 seeded, time-boxed slices of tests/fuzzlib.py under `pytest -m gpu`, and the end-to-end mismatch report written to
-profiles/r5_parity_report.json (also gpurun_out/, which is what comes back from the GPU box)."""
+profiles/r6_parity_report.json (also gpurun_out/, which is what comes back from the GPU box)."""
 import json
 import os
 import sys
@@ -19,10 +19,10 @@ def test_fuzz_general_graphs_slice(ctx, seed):
     epsilon-input arcs with words, unreachable finals, empty graphs, too-short utterances, narrow beams, retries,
     max_active) -- every assertion is inside fuzzlib.fuzz_graphs."""
     import fuzzlib
-    r = fuzzlib.fuzz_graphs(ctx, budget=15.0, seed=seed)
-    assert r["batches"] >= 20 and r["utterances"] >= 100, r
+    r = fuzzlib.fuzz_graphs(ctx, budget=10.0, seed=seed)
+    assert r["batches"] >= 15 and r["utterances"] >= 80, r
     assert r["fallback"] > 0 and r["retried"] > 0 and r["oracle_failed"] > 0, r      # the slice reaches the order-faithful decoders, retries and failures
-    assert r["band_batches"] >= 5, r                                                 # ... and K1's band form + repair on the same random graphs
+    assert r["band_batches"] >= 3, r                                                 # ... and K1's band form + repair on the same random graphs
 
 
 @pytest.mark.parametrize("seed", [303, 404])
@@ -30,7 +30,7 @@ def test_fuzz_parity_slice(ctx, seed):
     """Random shapes (G 1..128, D 1..80, ragged pdfs) and beams: K1 within 1e-5 + 1e-6 B of fp64, K2 bit-exact on
     identical scores, K3 within rtol 2e-4, K4 parameters bit-exact and gconsts <= 4 ulp vs the oracle."""
     import fuzzlib
-    r = fuzzlib.fuzz_parity(ctx, budget=20.0, seed=seed)
+    r = fuzzlib.fuzz_parity(ctx, budget=13.0, seed=seed)
     assert r["configurations"] >= 5 and r["utterances"] >= 20, r
 
 
@@ -50,7 +50,7 @@ def test_end_to_end_against_oracle_with_mismatch_report(ctx):
     rep["runs"] += [dict(r, scoring_model=hard["scoring_model"]) for r in hard["runs"]]
     for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
-            with open(os.path.join(d, "r5_parity_report.json"), "w") as fh:
+            with open(os.path.join(d, "r6_parity_report.json"), "w") as fh:
                 json.dump(rep, fh, indent=1)
     assert rep["frames"] > 60000
     for run in rep["runs"]:

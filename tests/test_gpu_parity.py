@@ -56,7 +56,7 @@ def test_loglikes_vs_oracle(ctx, P, G, D, ragged, k1_form):
         assert (np.abs(got[u] - want) <= 2 * tol).all()
     print("worst err/tol", worst)
 
-@pytest.mark.parametrize("k1", ["f16x2s", "f16x2", "bf16x3", "pdf", "utt"])
+@pytest.mark.parametrize("k1", ["f16x2s", "f16x2", "pdf", "utt"])
 @pytest.mark.parametrize("P,G,D", [(30, 64, 40), (24, 20, 13), (12, 128, 80)])
 def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, opt):
     """Same bound with the means pulled together (many components contribute to every log-sum-exp instead of one)."""
@@ -90,11 +90,10 @@ def test_loglikes_overlapping_gaussians(ctx, P, G, D, k1, opt):
     assert np.mean(spread) > 0.5
 
 
-@pytest.fixture(params=["f16x2s", "f16x2", "bf16x3", "pdf", "utt"])
+@pytest.fixture(params=["f16x2s", "f16x2", "pdf", "utt"])
 def k1_form(request, opt):
     """Every K1 form: f16x2s (the default: fp16 matrix cores, 3 partial products into one accumulator, feature tiles in LDS and
-    pdfs dealt to waves), f16x2 (the same products, two accumulators, frame tiles dealt to waves), bf16x3 (bf16 matrix cores, 6
-    partial products) and the two fp32-MFMA tilings, pdf-major and utterance-major."""
+    pdfs dealt to waves), f16x2 (the same products, two accumulators, frame tiles dealt to waves) and the two fp32-MFMA tilings, pdf-major and utterance-major."""
     opt.k1(request.param)
     return request.param
 
@@ -146,7 +145,7 @@ def test_loglikes_wide_dynamic_range(ctx, D, G, k1_form):
 
 def test_loglikes_f16x2_rescale_and_fallback(ctx, opt):
     """The f16x2 form keeps the set's feature planes while the next model fits their scales, re-packs them when it does
-    not, and hands over to the bf16x3 form (exact split, fp32's exponent range) when no scaling fits fp16."""
+    not, and hands over to the fp32-MFMA form (fp32's exponent range) when no scaling fits fp16."""
     import dataclasses
     from kaldi_hmm_gmm_amd import DeviceModel
 
@@ -180,7 +179,7 @@ def test_loglikes_f16x2_rescale_and_fallback(ctx, opt):
     _check_ll(us, dm_c, m_c, gc_c, ut)
     k = kernels()
     assert "k1h_pack_x" in k and "k0h_pack_tiles" in k
-    # inverse variance 1e12 against features of order 1: |w x^2| ~ 1e13 > 2^30 -> bf16x3 takes over, still inside the bound
+    # inverse variance 1e12 against features of order 1: |w x^2| ~ 1e13 > 2^30 -> the fp32-MFMA form takes over, still inside the bound
     s[5] = 1e-6
     m_d, gc_d, _ = _rescaled(m, ut, s)
     dm_d = DeviceModel(ctx, m_d.gauss_off, gc_d, m_d.means_invvars, m_d.inv_vars)
@@ -247,7 +246,7 @@ def test_two_contexts_on_two_streams_share_one_model(ctx):
     sc = np.ones(40, np.float32); sc[::2] = 4.0; sc[1::2] = 0.25
     ut_c = dataclasses.replace(ut, feats=(ut.feats * sc).astype(np.float32))
     us_b = UtteranceSet(ctx2, tm, ut_c.frame_off, ut_c.feats, graphs=ut.graphs)
-    for form in ("f16x2s", "f16x2", "bf16x3"):
+    for form in ("f16x2s", "f16x2"):
         ctx.set_k1_form(form); ctx2.set_k1_form(form)
         for c in (ctx, ctx2):
             c.sync(); c.set_timing(True); c.timings()

@@ -39,7 +39,7 @@ def test_em_pass_properties_at_bench_shape(ctx, opt, P, G, D, U, seed):
     tm.set_trans_cost(cost)
     us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
 
-    # ---- K1: two fp32-MFMA tilings, one answer; the bf16x3 form (the default) within the fp32 bound of them ----
+    # ---- K1: two fp32-MFMA tilings, one answer; the f16x2s form (the default) within the fp32 bound of them ----
     opt.k1("pdf")
     us.loglikes(dm)
     ll = us.download_loglikes()

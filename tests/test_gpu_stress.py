@@ -46,7 +46,7 @@ def test_config5_em_pass_properties(ctx, stress, opt):
     m, gc, ut, cost, dm, tm, us = stress
     N = int(ut.frame_off[-1])
     assert N > 250000
-    # ---- K1: two fp32-MFMA tilings, one answer; the bf16x3 form (the default) checked against fp64 below ----
+    # ---- K1: two fp32-MFMA tilings, one answer; the f16x2s form (the default) checked against fp64 below ----
     opt.k1("pdf")
     us.loglikes(dm)
     ll = us.download_loglikes()
