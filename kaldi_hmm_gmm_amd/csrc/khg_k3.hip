@@ -51,8 +51,8 @@ extern "C" int khg_accs_upload(khg_ctx* ctx, khg_accs* a, const double* buf) {
 // evaluated at xb, above 4e-6; |S| > 40; the log-sum-exp's 2^28 bound at 16 xb) or when a feature of THIS set overflows fp16.
 static int k3_phase_a_scales(khg_ctx* ctx, khg_model* m, khg_utts* u, bool* use) {
   *use = false;
-  const int D = m->D, K = 80;
-  if (m->KQ != 10 || D > 40) return KHG_OK;
+  const int D = m->D, K = 8 * m->KQ;           // 80 exponents at D <= 40 (the wave forms), 160 at D <= 80 (k3_accumulate_block16)
+  if (m->KQ == 0) return KHG_OK;
   std::vector<float> xk;
   int rc = k1_maxima(ctx, m, u, &xk);          // the set's column maxima (cached) and the model's (wmax, gcmax; cached per version)
   if (rc) return rc;
@@ -305,6 +305,26 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
       if (ctx->opt[KHG_OPT_K3_NY] > 0) ny = ctx->opt[KHG_OPT_K3_NY];
       rc = make_items(ny, false, 0, cls_lo, cls_hi, second);
       if (rc) return rc;
+      // Both phases on the fp16 matrix cores (k3_accumulate_block16) where the model-derived scales hold and the weight is an ordinary
+      // number (the conditions of the wave form's fp16 phases): <= 128 Gaussians at D <= 80, <= 192 at D <= 40.  KHG_K3_PHASEA=f32 or
+      // KHG_K3_PHASEB=f64 keep the fp32 / fp64 MFMA form.
+      bool b16 = false;
+      if (ctx->opt[KHG_OPT_K3_PHASE_A] == 0 && ctx->opt[KHG_OPT_K3_PHASE_B] == 2 && ((m->KQ == 20 && maxG <= 128) || (m->KQ == 10 && maxG <= 192)) &&
+          std::isfinite(weight) && std::fabs(weight) > 1.0e-30f && std::fabs(weight) < 1.0e30f) {
+        rc = k3_phase_a_scales(ctx, const_cast<khg_model*>(m), u, &b16);
+        if (rc) return rc;
+      }
+      if (b16) {
+        a.pa_ex = m->k3_ex_d; a.pa_S = m->k3_S;
+        a.pa_scale = std::ldexp(1.0f, m->k3_S); a.pa_inv = std::ldexp(1.0f, -m->k3_S); a.pa_c1 = std::ldexp(1.44269504088896340736f, -m->k3_S);
+        a.pb_SG = 13 - std::ilogb(std::fabs(weight)); a.pb_gscale = std::ldexp(1.0f, a.pb_SG);
+      }
+      // split planes of a chunk in both layouts + the softmax's exchange: [2][64][KPAD + 8] + [2][2 XP][72] halves, 5 x 64 floats
+      const size_t kpad = ((size_t)8 * m->KQ + 31) / 32 * 32;
+      // ... or, before the chunk loop, the pdf's parameter rows [2][lanes' Gaussians][D | 1] + the columns' exponents
+      const size_t gp_b16 = maxG <= 64 ? 64 : (maxG <= 128 ? 128 : 192);
+      const size_t lds_b16 = std::max<size_t>(2 * (2 * (size_t)K3_CHUNK * (kpad + 8) + 2 * (size_t)8 * m->KQ * (K3_CHUNK + 8)) + sizeof(float) * 9 * K3_CHUNK,
+                                              sizeof(float) * (2 * gp_b16 * (size_t)(m->D | 1) + 8 * (size_t)m->KQ));
       const int nparts_ = comm_ ? nparts : 1;
       for (int part = 0; part < nparts_; ++part) {
         const int p0 = (int)((int64_t)m->P * part / nparts_), np = (int)((int64_t)m->P * (part + 1) / nparts_) - p0;
@@ -312,6 +332,18 @@ static int acc_stats_pass(khg_ctx* ctx, const khg_model* m, const khg_tm* tm, kh
         const unsigned nblk = (unsigned)((int64_t)std::min(np, n_cls) * ny + k3_extra_blocks);
         {
           KernelTimer kt(ctx, nsub < 0 ? "k3_accumulate" : "k3_accumulate_pass2");
+          if (b16) {
+#define K3_B16(KQV, NBWV, NWVV)                                                                                                 \
+  do {                                                                                                                          \
+    HIPCHK(hipFuncSetAttribute((const void*)k3_accumulate_block16<KQV, NBWV, NWVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b16)); \
+    KHG_LAUNCH(ctx, (k3_accumulate_block16<KQV, NBWV, NWVV>), dim3(nblk), dim3(64 * NWVV), lds_b16, ctx->stream, a);            \
+  } while (0)
+            // (one Gaussian block per wave: < 256 registers, so a block of eight waves runs two per SIMD)
+            if (maxG <= 64) { if (m->KQ == 20) K3_B16(20, 1, 4); else K3_B16(10, 1, 4); }
+            else if (maxG <= 128) { if (m->KQ == 20) K3_B16(20, 1, 8); else K3_B16(10, 1, 8); }
+            else K3_B16(10, 3, 4);         // (four blocks per wave -- 193..256 Gaussians -- spill at 512 registers: the fp32 / fp64 form keeps them)
+#undef K3_B16
+          } else
           if (m->KQ == 10 && maxG <= 64) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 1>), dim3(nblk), dim3(256), lds, ctx->stream, a);
           else if (m->KQ == 10 && maxG <= 128) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 2>), dim3(nblk), dim3(256), lds, ctx->stream, a);
           else if (m->KQ == 10 && maxG <= 192) KHG_LAUNCH(ctx, (k3_accumulate_mfma<10, 3>), dim3(nblk), dim3(256), lds, ctx->stream, a);
