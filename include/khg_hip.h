@@ -88,7 +88,7 @@ int khg_ctx_set_k1_form(khg_ctx *ctx, int form);     /* = khg_ctx_set_option(ctx
  * kept.  The environment variables in brackets only seed the defaults, once, at khg_ctx_create (A/B runs of an unmodified caller). */
 #define KHG_OPT_K1_FORM 0        /* KHG_K1_* above                                                              [KHG_K1=f16x2s|f16x2|pdf|utt] */
 #define KHG_OPT_K1_ORDER 1       /* launch order of K1 workgroups: 0 frame tiles x pdfs descending, 1 utterance order, 2 ascending,
-                                    3 frame tiles descending                                                    [KHG_K1_ORDER=desc|none|asc|tiles] */
+                                    3 frame tiles descending, 4 the chunks of one utterance eight positions apart (one XCD)  [KHG_K1_ORDER=desc|none|asc|tiles|xcd] */
 #define KHG_OPT_K1_NF 2          /* fp32 utterance-major K1: 16-frame tiles per wave at D <= 40 (0 = 6, or 5)     [KHG_K1_NF] */
 #define KHG_OPT_K1P_TS 3         /* fp32 pdf-major K1: tiles per workgroup slice (default 1024)                  [KHG_K1P_TS] */
 #define KHG_OPT_K1_INTERLEAVE 4  /* fp32 utterance-major K1: frame tiles dealt round-robin (-1 auto, 0, 1)        [KHG_K1_INTERLEAVE] */

@@ -168,7 +168,7 @@ extern "C" int khg_ctx_get_timings(khg_ctx* c, char* names, int64_t names_cap, f
 }
 // valid range of every option (inclusive)
 static const struct { int lo, hi; } k_opt_range[KHG_OPT_COUNT] = {
-  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 3}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 3}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}, {0, 1}};
+  {KHG_K1_AUTO, KHG_K1_F16X2S}, {0, 4}, {0, 6}, {0, 1 << 20}, {-1, 1}, {0, 255}, {0, 1}, {0, 4}, {0, 3}, {0, 1}, {0, 2}, {0, 2}, {0, 2}, {0, 64}, {0, 1}, {0, 1}, {0, 1}};
 extern "C" int khg_ctx_set_option(khg_ctx* c, int opt, int value) {
   if (!c || opt < 0 || opt >= KHG_OPT_COUNT) return khg_set_error(KHG_E_ARG, "khg_ctx_set_option: bad arguments");
   if (value < k_opt_range[opt].lo || value > k_opt_range[opt].hi || (opt == KHG_OPT_K1_FORM && value == 1))      // (1: the removed bf16x3 form)
@@ -191,7 +191,7 @@ extern "C" int khg_ctx_set_k1_form(khg_ctx* c, int form) { return khg_ctx_set_op
 static void ctx_defaults_from_env(khg_ctx* c) {
   static const struct { const char* name; int opt; const char* words; } tab[] = {
     {"KHG_K1", KHG_OPT_K1_FORM, "auto=0,pdf=2,fp32=2,utt=3,f16x2=4,f16x2s=5"},
-    {"KHG_K1_ORDER", KHG_OPT_K1_ORDER, "desc=0,none=1,asc=2,tiles=3"},
+    {"KHG_K1_ORDER", KHG_OPT_K1_ORDER, "desc=0,none=1,asc=2,tiles=3,xcd=4"},
     {"KHG_K1_NF", KHG_OPT_K1_NF, ""}, {"KHG_K1P_TS", KHG_OPT_K1P_TS, ""}, {"KHG_K1_INTERLEAVE", KHG_OPT_K1_INTERLEAVE, ""},
     {"KHG_K1B_DBG", KHG_OPT_K1_DBG, ""}, {"KHG_K2_INORDER", KHG_OPT_K2_INORDER, ""}, {"KHG_K2_KS", KHG_OPT_K2_KS, ""},
     {"KHG_K2_SERIAL", KHG_OPT_K2_SERIAL, ""}, {"KHG_K2_PROF", KHG_OPT_K2_PROF, ""},

@@ -223,7 +223,35 @@ static void plan_x32_chunks(const khg_utts* u, int per, int order, std::vector<C
       if (t1 > t0) ch->push_back(Chunk{i, t0, t1 - t0, 0});
     }
   }
-  // KHG_OPT_K1_ORDER (experiments): 0 frame tiles x pdfs descending (default), 1 utterance order, 2 ascending, 3 frame tiles descending
+  // KHG_OPT_K1_ORDER (experiments): 0 frame tiles x pdfs descending (default), 1 utterance order, 2 ascending, 3 frame tiles descending,
+  // 4 the chunks of ONE utterance eight positions apart: workgroups go to the eight XCDs round-robin, so siblings -- which walk the same
+  // pdf list, i.e. the same W tiles, at about the same time -- share an L2 (the second one's W loads need not come from HBM)
+  if (order == 4) {
+    std::vector<int32_t> first(1, 0);                       // chunks are grouped by utterance: first[i] = first chunk of group i
+    for (size_t i = 1; i < ch->size(); ++i) if ((*ch)[i].utt != (*ch)[i - 1].utt) first.push_back((int32_t)i);
+    first.push_back((int32_t)ch->size());
+    const int ng = (int)first.size() - 1;
+    std::vector<int32_t> grp((size_t)ng);
+    for (int i = 0; i < ng; ++i) grp[(size_t)i] = i;
+    auto gcost = [&](int g) { int64_t t = 0; for (int k = first[(size_t)g]; k < first[(size_t)g + 1]; ++k) t += (*ch)[(size_t)k].ntiles; return t * (u->pdf_off[(*ch)[(size_t)first[(size_t)g]].utt + 1] - u->pdf_off[(*ch)[(size_t)first[(size_t)g]].utt]); };
+    auto gn = [&](int g) { return first[(size_t)g + 1] - first[(size_t)g]; };
+    std::stable_sort(grp.begin(), grp.end(), [&](int a, int b) { return gn(a) != gn(b) ? gn(a) > gn(b) : gcost(a) > gcost(b); });
+    std::vector<Chunk> out;
+    out.reserve(ch->size());
+    for (int b = 0; b < ng; b += 8) {                       // a band of eight utterances: round r = chunk r of each
+      const int nb = std::min(8, ng - b);
+      int rounds = 0;
+      for (int i = 0; i < nb; ++i) rounds = std::max(rounds, gn(grp[(size_t)(b + i)]));
+      for (int r = 0; r < rounds; ++r)
+        for (int i = 0; i < nb; ++i) {
+          const int g = grp[(size_t)(b + i)];
+          if (r < gn(g)) out.push_back((*ch)[(size_t)(first[(size_t)g] + r)]);
+          else out.push_back(Chunk{(*ch)[(size_t)first[(size_t)g]].utt, 0, 0, 0});      // (an empty workgroup keeps the band's XCD alignment)
+        }
+    }
+    ch->swap(out);
+    return;
+  }
   auto cost = [&](const Chunk& c) { return (int64_t)c.ntiles * (order == 3 ? 1 : (u->pdf_off[c.utt + 1] - u->pdf_off[c.utt])); };
   if (order == 2) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) < cost(b); });
   else if (order != 1) std::stable_sort(ch->begin(), ch->end(), [&](const Chunk& a, const Chunk& b) { return cost(a) > cost(b); });
@@ -463,7 +491,10 @@ static int loglikes_f16x2s(khg_ctx* ctx, khg_model* m, khg_utts* u, int reach) {
     std::vector<K1sChunk> ch;
     // (one or two utterances -- the per-utterance call pattern -- cannot fill the chip with whole utterances: short chunks spread them
     //  over more workgroups; the W tiles are re-read per chunk from the cache, a band that crosses chunks keeps its aligned tiles)
-    plan_x32_chunks(u, (u->small && u->n_utt <= 2) ? std::min(NMAX, 3) : NMAX, ctx->opt[KHG_OPT_K1_ORDER], &ch);
+    // (D > 40: the W image does not fit the Infinity Cache and an utterance is two or three chunks -- their order puts siblings on one XCD:
+    //  K1 55.6 -> 52.2 ms at 10 000 x 128 x 80 / 20 000 utterances; at D <= 40 it changes nothing: 56.9 ms either way)
+    const int order = (ctx->opt[KHG_OPT_K1_ORDER] == 0 && KS == 10 && !u->small) ? 4 : ctx->opt[KHG_OPT_K1_ORDER];
+    plan_x32_chunks(u, (u->small && u->n_utt <= 2) ? std::min(NMAX, 3) : NMAX, order, &ch);
     rc = u_upload(ctx, u, &u->schunks_d, ch);
     if (rc) return rc;
     { int rs = sync_pageable(ctx); if (rs) return rs; }

@@ -275,3 +275,51 @@ def test_rccl_two_ranks_on_two_gpus(tmp_path):
         pytest.skip("needs >= 2 GPUs (RCCL does not form a communicator with two ranks on one device)")
     world = 2 if n < 4 else 4
     _check_rccl_ranks(_spawn("rccl", world, tmp_path), world)
+
+
+@pytest.mark.parametrize("nparts", [1, 4])
+def test_split_mode_and_mixed_classes_with_the_exchange_behind_k3(ctx, nparts):
+    """khg_acc_stats_reduce on a real (one-rank) RCCL communicator in the two situations where K3 is more than one launch sequence:
+    the SPLIT mode (order-faithful decoders still running: certified utterances first, the rest in a second pass -- the exchange's
+    pieces follow the SECOND pass) and a model with pdfs of two classes (wave form + chunk-per-block form: the pieces follow the
+    second class).  With one rank every sum is the identity: the block must equal the one khg_acc_stats leaves without an exchange."""
+    from kaldi_hmm_gmm_amd import Comm, DeviceAccs, DeviceModel, DeviceTransitions, UtteranceSet, synth
+    from oracle import oracle as orc
+    P, D, U = 90, 40, 200
+    counts = np.full(P, 64); counts[7] = 130; counts[40] = 100
+    m0 = synth.make_model(P, 64, D, seed=77, gauss_counts=counts)
+    ut = synth.make_utts(m0, U, seed=8, min_phones=4, max_phones=12)
+    m = m0
+    gc = orc.model_gconsts(m.gauss_off, m.weights, m.inv_vars, m.means_invvars)
+    il = np.arange(m.num_tids + 1, dtype=np.int32)
+    cost = orc.add_transition_probs(il, np.zeros(m.num_tids + 1, np.float32), m.log_probs, m.non_self_loop_log_probs, m.id2state, m.is_self_loop, 1.0, 0.1)
+    dm = DeviceModel(ctx, m.gauss_off, gc, m.means_invvars, m.inv_vars)
+    tm = DeviceTransitions(ctx, m.id2pdf)
+    tm.set_trans_cost(cost)
+    us = UtteranceSet(ctx, tm, ut.frame_off, ut.feats, graphs=ut.graphs)
+    poff, pdfs = us.pdf_lists()
+    rng = np.random.default_rng(4)
+    # scores that make a narrow beam prune: a good share of the utterances leaves the beam certificate
+    us.upload_loglikes([(-40.0 * rng.random((poff[u + 1] - poff[u], int(ut.frame_off[u + 1] - ut.frame_off[u])))).astype(np.float32) for u in range(U)])
+    comm = Comm(ctx, 1, 0, Comm.unique_id())
+    res = us.align(tm, beam=3.0, retry_beam=30.0, acoustic_scale=0.1)
+    n_fb = int((res["status"] & 8 != 0).sum())
+    assert 10 <= n_fb, n_fb
+    want = DeviceAccs(ctx, dm, tm)
+    us.acc_stats(dm, tm, want)                               # synchronous alignment above: one pass, no exchange
+    w = want.download()
+    for split in (0, 1):
+        old = ctx.set_option("k2_split", split)
+        try:
+            us.align(tm, beam=3.0, retry_beam=30.0, acoustic_scale=0.1, download=False)
+            got = DeviceAccs(ctx, dm, tm)
+            us.acc_stats_reduce(dm, tm, got, 1.0, comm, nparts)
+            g = got.download()
+        finally:
+            ctx.set_option("k2_split", old)
+        assert np.array_equal(np.asarray(us.download_ali()), res["ali"])
+        assert np.array_equal(g["trans_acc"], w["trans_acc"]) and g["total_frames"] == w["total_frames"]
+        for k in ("occ", "mean_acc", "var_acc"):
+            np.testing.assert_allclose(g[k], w[k], rtol=1e-6, atol=1e-6 * np.abs(w[k]).max(), err_msg=f"{k} split {split} nparts {nparts}")
+        got.close()
+    want.close(); comm.close(); us.close(); tm.close(); dm.close()

@@ -188,7 +188,7 @@ def test_config5_fp32_accumulator_exchange_vs_fp64(ctx, stress):
            "block_doubles": int(accs.size), "wire_bytes_fp64": int(accs.size) * 8, "wire_bytes_fp32": int(accs.size) * 4}
     for d_ in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d_):
-            with open(os.path.join(d_, "r5_fp32_accs_report.json"), "w") as fh:
+            with open(os.path.join(d_, "r6_fp32_accs_report.json"), "w") as fh:
                 json.dump(rep, fh, indent=1)
     # fp32 partial sums: 2^-24 relative per rounding, a few roundings per cell.  Means ~ +-10: 1e-5 absolute; the variance
     # is the difference E[x^2] - mu^2 of quantities up to ~100x larger than itself, so it is bounded in absolute terms
