@@ -367,7 +367,7 @@ def test_align_end_to_end(ctx):
 
 
 @pytest.mark.parametrize("k3_form", ["wave", "wave_f32", "block", "valu"])
-@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (30, 40, 13, True), (12, 128, 80, False)])
+@pytest.mark.parametrize("P,G,D,ragged", [(30, 8, 39, True), (30, 64, 40, False), (30, 40, 13, True), (12, 128, 80, False), (10, 100, 77, True)])
 def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
     """All three K3 accumulate kernels: the wave-local MFMA form (default for <= 64 Gaussians, D <= 40; its per-Gaussian
     log-likelihoods on the fp16 matrix cores in K1's f16x2s arithmetic -- "wave" -- or as the fp32 MFMA chain -- "wave_f32",
@@ -402,14 +402,15 @@ def test_acc_stats_vs_oracle(ctx, P, G, D, ragged, k3_form, opt):
     np.testing.assert_allclose(got["var_acc"], oa.var_acc, rtol=2e-5, atol=2e-6 * np.abs(oa.var_acc).max())
 
 
+@pytest.mark.parametrize("D", [40, 39])
 @pytest.mark.parametrize("big", [(130,), (70, 256), (300,)])
-def test_acc_stats_form_is_chosen_per_pdf(ctx, big):
+def test_acc_stats_form_is_chosen_per_pdf(ctx, big, D):
     """A model whose pdfs hold <= 64 Gaussians except for a few that Split (csrc/diag-gmm.cc:780-851) has grown: the wave form keeps
     every pdf it can take, only the grown ones go to the chunk-per-block MFMA form (<= 256 Gaussians) or the VALU form (beyond) --
     one launch per class, the same accumulator block.  Against the oracle (csrc/mle-diag-gmm.cc:123-158, csrc/diag-gmm.cc:368-392);
     the <= 64-Gaussian pdfs' statistics are bit-identical to those of the same pdfs in a model without the grown ones' frames."""
     from kaldi_hmm_gmm_amd import DeviceAccs
-    P, D = 45, 40
+    P = 45
     counts = np.full(P, 64)
     counts[::7] = 33
     for k, g in enumerate(big):
