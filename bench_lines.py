@@ -433,8 +433,10 @@ def recipe_and_flat_start_lines(B):
     recipe_line = None
     flat_line = None
     if not args.no_recipe_beam_line and args.beam != 6.0:
+        nside = max(1, int(os.environ.get("KHG_BENCH_SIDE_STEPS", "2")))      # timed steps of the two side lines (2; more for an A/B of their difference)
+
         def recipe_steps(dmodel):
-            """Two timed steps at beam 6 / retry 40 with `dmodel` -> (seconds, kernel ms, [retried, fallback, failed] utterances over all ranks)."""
+            """`nside` timed steps at beam 6 / retry 40 with `dmodel` -> (seconds, kernel ms, [retried, fallback, failed] utterances over all ranks)."""
             def step_recipe(download=False):
                 accs.zero()
                 dmodel.invalidate()
@@ -455,7 +457,7 @@ def recipe_and_flat_start_lines(B):
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(nside):
                 step_recipe()
             torch.cuda.synchronize()
             if dist_on:
@@ -473,7 +475,7 @@ def recipe_and_flat_start_lines(B):
             if dist_on:
                 mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
                 dtr = float(mx[0])
-            return dtr, {k: v / 2 for k, v in sorted(kr.items())}, [int(cnt[1]), int(cnt[2]), int(cnt[3])]
+            return dtr * 2 / nside, {k: v / nside for k, v in sorted(kr.items())}, [int(cnt[1]), int(cnt[2]), int(cnt[3])]
 
         dtr, kr, cnt = recipe_steps(dm)
         recipe_line = {"beam": 6.0, "retry_beam": 40.0, "k1_cells": "khg_loglikes_reachable (no band)", "steps": 2, "ms_per_step": dtr / 2 * 1e3,
