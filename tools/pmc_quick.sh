@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmcq_${2:-a}
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc $1 --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-line > /dev/null 2> $OUT/log.txt
+rocprofv3 --pmc $1 --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-line --per-call-utts 0 --no-recipe-beam-line > /dev/null 2> $OUT/log.txt
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*_counter_collection.csv")[0]
