@@ -255,7 +255,9 @@ int khg_careful_graph(int32_t num_states, int32_t start, const int64_t *arc_off_
  *   words_h / words_off_h[n_utt+1]: olabels != 0 along the best path (words_cap = capacity)
  *   like_h[n_utt]   float `like` of decoder-wrappers.cc:95
  *   status_h[n_utt] KHG_ALIGN_* bits.
- * The alignment also stays resident on the device for khg_acc_stats. */
+ * The alignment also stays resident on the device for khg_acc_stats.  With every host output NULL the call is asynchronous: the exact
+ * DP runs on the context's stream, the order-faithful decoders for the utterances it could not certify on a side stream; on a set of
+ * more than 64 utterances those write to a second alignment buffer that the next consumer merges (KHG_OPT_K2_SPLIT). */
 int khg_align(khg_ctx *ctx, const khg_tm *tm, khg_utts *u, const khg_align_config *cfg,
               int32_t *ali_h, int32_t *words_h, int64_t *words_off_h, int64_t words_cap,
               float *like_h, int32_t *status_h);
@@ -281,7 +283,11 @@ int khg_accs_upload(khg_ctx *ctx, khg_accs *a, const double *buf_h);
 /* scripts/gmm_acc_stats_ali.py:46-56 for every frame of every utterance with a resident
  * alignment: AccumAmDiagGmm::AccumulateForGmm (csrc/mle-am-diag-gmm.cc:41-52) ->
  * AccumDiagGmm::AccumulateFromDiag/FromPosteriors (csrc/mle-diag-gmm.cc:123-158) ->
- * DiagGmm::ComponentPosteriors (csrc/diag-gmm.cc:368-392), plus tacc[tid] += 1. */
+ * DiagGmm::ComponentPosteriors (csrc/diag-gmm.cc:368-392), plus tacc[tid] += 1.
+ * Asynchronous on the context's stream.  Right behind an asynchronous khg_align on a large set the call waits ONCE for the exact DP
+ * (not for the order-faithful decoders, not for its own kernels) to learn whether any utterance was left to those decoders; if so
+ * the certified utterances are accumulated at once and the others in a second pass when the decoders are done (the statistics are
+ * additive, csrc/mle-am-diag-gmm.cc:41-52; KHG_OPT_K2_SPLIT = 1: one pass after the decoders). */
 int khg_acc_stats(khg_ctx *ctx, const khg_model *m, const khg_tm *tm, khg_utts *u, float weight,
                   khg_accs *a);
 
