@@ -141,9 +141,11 @@ extern "C" int khg_align(khg_ctx* ctx, const khg_tm* tm, khg_utts* u, const khg_
   // graph): a third of the wave form's latency per frame.  KHG_K2_SERIAL = 3: the general wave form also where the chain form applies.
   const int odeg_c = (int)std::max<int32_t>(1, u->max_outdeg);
   const size_t S4 = (S + 3) & ~size_t(3);
-  // token costs x 2 + state keys (24) | token states x 2 (8) | first / winner (8) | GetCutoff array (4) | in-arc offsets (4): 48 per state;
-  // per out-arc slot: parked cost (8) + record (8) + info (4) + ordinal (1); score row; in-arc sources (2 per arc); the trace-back's 9 rows
-  const size_t lds_chain = 48 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf + 2 * A + 9 * ((S + 15) & ~size_t(15)) + 128;
+  // the frame loop's tables: token costs x 2 + state keys (24) | first / winner (8) | token states x 2 (4): 36 per state; per out-arc slot:
+  // parked cost (8) + record (8) + info (4, GetCutoff's array over it) + ordinal (1); the score row.  Over them, set-up and tail only:
+  // in-arc offsets (4 per state) + sources (2 per arc) + the trace-back's 9 rows.
+  const size_t lds_chain = std::max<size_t>(36 * S4 + 21 * S4 * (size_t)odeg_c + 4 * max_npdf,
+                                            4 * (S4 + 1) + 2 * A + 16 + 9 * ((S + 15) & ~size_t(15))) + 128;
   const bool chain = fmode == 0 && !u->has_eps && S <= 1000 && u->max_outdeg <= 4 && lds_chain <= 64 * 1024 && max_npdf <= 32767;
   const bool wave_lds = (fmode == 0 || fmode == 3) && S <= 65535 && lds_w_mut + lds_w_graph <= 160 * 1024;
   const bool wave_gm = fmode != 1 && !wave_lds && S <= 65535 && lds_w_mut <= 160 * 1024;
