@@ -35,3 +35,28 @@ def test_transcript_laws_change_the_overlap_and_the_skew_not_the_graph_shape():
     assert shared["zipf"] > 1.3 * shared["uniform"]
     per = np.bincount(uts["skew"].frame_pdf, minlength=600)
     assert per[:3].min() > 30 * np.median(per)        # half of all phones are phone 0
+
+
+def test_mismatched_model_trades_whole_pdfs_and_nothing_else():
+    """The scoring model of the flat-start line and the hard-regime tests: a seeded fraction of the pdfs trade ALL their parameters
+    among themselves (no pdf keeps its own, none is lost), everything else -- transition-ids, the other pdfs -- is untouched."""
+    m = synth.make_model(60, 4, 5, seed=3)
+    mm = synth.mismatched_model(m, 0.3, seed=7)
+    G = 4
+    rows = lambda a, p: a[p * G:(p + 1) * G]
+    moved = [p for p in range(60) if not np.array_equal(rows(mm.means_invvars, p), rows(m.means_invvars, p))]
+    assert 5 <= len(moved) <= 35                                   # ~ 0.3 of 60
+    for p in range(60):
+        src = [q for q in range(60) if np.array_equal(rows(mm.means_invvars, p), rows(m.means_invvars, q))]
+        assert len(src) == 1
+        q = src[0]
+        assert (q != p) == (p in moved)
+        for name in ("weights", "inv_vars", "means", "vars"):
+            assert np.array_equal(rows(getattr(mm, name), p), rows(getattr(m, name), q)), name
+    # a permutation of the moved set: every traded pdf's parameters are still somewhere
+    srcs = sorted(next(q for q in range(60) if np.array_equal(rows(mm.means_invvars, p), rows(m.means_invvars, q))) for p in moved)
+    assert srcs == sorted(moved)
+    assert np.array_equal(mm.gauss_off, m.gauss_off) and np.array_equal(mm.id2pdf, m.id2pdf)
+    again = synth.mismatched_model(m, 0.3, seed=7)
+    assert np.array_equal(again.means_invvars, mm.means_invvars)
+    assert np.array_equal(synth.mismatched_model(m, 0.0, seed=7).means_invvars, m.means_invvars)
